@@ -1,0 +1,179 @@
+/*
+ * mau_hip.h -- C ABI of libmau_hip.so: the MI355X (gfx950) hot path of the
+ * Metadata-Augmented U-Net (forward + backward of src/model.py as driven by
+ * src/train.py:243-256 in the reference repository).
+ *
+ * Boundary rules:
+ *   - plain pointers and sizes only, no torch / C++ types;
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (the caller passes its current stream);
+ *   - no hidden allocation, no retained pointers: every workspace is an argument;
+ *   - re-entrant per stream; safe to capture into a hipGraph (no sync, no malloc);
+ *   - return value: 0 = ok, non-zero = error (message via mau_last_error()).
+ *
+ * Internal activation layout ("NHWC-ld"): element (n, y, x, c) of a tensor lives at
+ *   base + ((n*H + y)*W + x)*ld + c,   ld % 8 == 0,  ld >= C,
+ * and channels [C, roundup(C,8)) are always zero.  `dtype` selects the arithmetic type of
+ * activations and packed weights: MAU_F32 (parity mode, exact fp32 MFMA) or
+ * MAU_BF16 (throughput mode, bf16 MFMA with fp32 accumulation).  Parameters,
+ * gradients of parameters, BatchNorm statistics and the model's external
+ * inputs/outputs are always fp32 in the reference's own layouts (NCHW, OIHW).
+ *
+ * Each entry point names the reference code it replaces (file:line in the
+ * reference repo).
+ */
+#ifndef MAU_HIP_H
+#define MAU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAU_F32 0
+#define MAU_BF16 1
+
+#define MAU_OK 0
+#define MAU_ERR_ARG 1      /* bad argument (shape, alignment, dtype)      */
+#define MAU_ERR_HIP 2      /* a HIP runtime call / kernel launch failed   */
+#define MAU_ERR_DEVICE 3   /* no gfx950 device                             */
+
+typedef void* mau_stream_t;
+
+/* ---- library ---------------------------------------------------------- */
+int mau_abi_version(void);
+const char* mau_last_error(void);
+/* 0 when the current HIP device is a gfx950 (MI355X); MAU_ERR_DEVICE otherwise. */
+int mau_device_check(void);
+
+/* ---- layout at the module boundary ------------------------------------ */
+/* maps (B,C,H,W) fp32 as handed over by collate_fn (src/dataset.py:99-106) -> NHWC-ld. */
+int mau_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int ld,
+                     mau_stream_t stream);
+/* inverse (tests, debugging, gradient w.r.t. maps). */
+int mau_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int ld,
+                     mau_stream_t stream);
+
+/* ---- 3x3 convolution, stride 1, pad 1 (nn.Conv2d(.,.,3,padding=1), src/model.py:12,14) ---- */
+/* Channel-chunk size of the packed weights for `dtype` (K-chunk of the implicit GEMM). */
+int mau_conv3x3_kc(int dtype);
+/* Elements (of `dtype`) of a packed weight buffer with `nout` output and `nin` input channels. */
+size_t mau_conv3x3_packed_elems(int dtype, int nout, int nin);
+/* OIHW fp32 weights (Cout,Cin,3,3) -> forward pack `wf` [Cin/KC][9][Cout64][KC] and (optional,
+ * may be NULL) data-gradient pack `wd` [Cout/KC][9][Cin64][KC] (taps rotated by 180 degrees). */
+int mau_conv3x3_pack_weights(const float* w_oihw, void* wf, void* wd, int dtype, int Cout, int Cin,
+                             mau_stream_t stream);
+/* Number of pixel tiles (= rows of the BatchNorm partial-statistics slab) for an N x H x W image batch. */
+int mau_conv3x3_num_pixel_tiles(int N, int H, int W);
+/* y = conv3x3(cat([x, broadcast(emb)], C)) + bias.
+ *   x     NHWC-ld with C0 channels;
+ *   emb   optional fp32 (N,E): E extra input channels, constant over (y,x) inside the image and
+ *         zero in the padding halo -- fuse_embeddings (src/model.py:248-259) without ever
+ *         materialising the tiled map; NULL/E=0 for ordinary convolutions;
+ *   wpk   forward pack for Cin = C0+E;  bias fp32 (Cout) or NULL;
+ *   slab  optional fp32 [num_pixel_tiles][2][Cout64]: per-tile sum / sum of squares of y over the
+ *         tile's valid pixels (first half of train-mode nn.BatchNorm2d, src/model.py:13,15).
+ * The same entry point computes the data gradient when given dy and the `wd` pack. */
+int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, int E, const void* wpk,
+                    const float* bias, void* y, int ldy, int Cout, float* slab, int dtype, int N, int H,
+                    int W, mau_stream_t stream);
+/* dW += x (*) dy:  acc fp32 [9][Cout64][Cin64] (zeroed by this call), reduced over all pixels.
+ * x is the convolution's input (with the optional broadcast `emb` as in mau_conv3x3_fwd). */
+int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, int E, const void* dy, int lddy,
+                      int Cout, float* acc, int dtype, int N, int H, int W, mau_stream_t stream);
+size_t mau_conv3x3_wgrad_acc_elems(int Cout, int Cin);
+/* acc [9][Cout64][Cin64] -> dw OIHW fp32 (Cout,Cin,3,3). */
+int mau_conv3x3_unpack_wgrad(const float* acc, float* dw_oihw, int Cout, int Cin, mau_stream_t stream);
+
+/* ---- BatchNorm2d (+ReLU) (src/model.py:13,15,16) ------------------------ */
+/* slab [rows][M] fp32 -> sums[M] fp64 (column sums, deterministic order). */
+int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, mau_stream_t stream);
+/* slab [rows][M] fp32 -> out[M] fp32 (column sums accumulated in fp64). */
+int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, mau_stream_t stream);
+/* Train mode: sums = [sum(y) | sum(y^2)] (2*C fp64, already all-reduced over ranks when data
+ * parallel), count = number of pixels summed.  Writes scale = gamma*invstd, shift = beta - mean*scale,
+ * mean, invstd and updates running_mean / running_var (unbiased) / num_batches_tracked exactly as
+ * nn.BatchNorm2d(momentum, eps).forward does in training. */
+int mau_bn_finalize_train(const double* sums, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          float momentum, float eps, float* scale, float* shift, float* mean,
+                          float* invstd, int C, mau_stream_t stream);
+/* Eval mode: scale/shift from the running statistics (mean/invstd outputs optional, may be NULL). */
+int mau_bn_coeffs_eval(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, float* mean,
+                       float* invstd, int C, mau_stream_t stream);
+/* a = relu(scale*y + shift) on NHWC-ld (pad channels written as 0). */
+int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift, void* a, int lda,
+                      int dtype, int64_t npix, int C, mau_stream_t stream);
+/* Backward, pass 1: dz = da * [scale*y+shift > 0]; per-block partial sums of dz and dz*xhat
+ * (xhat = (y-mean)*invstd) into slab [rows][2][ldslab]; returns rows via *rows_out (host). */
+int mau_bn_relu_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale,
+                           const float* shift, const float* mean, const float* invstd, float* slab,
+                           int ldslab, int dtype, int64_t npix, int C, mau_stream_t stream);
+/* Backward, pass 2: dy = scale*(dz - s1/count - xhat*s2/count); sums = [s1 | s2] fp64 (2*C). */
+int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, const double* sums,
+                          double count, void* dy, int lddy, int dtype, int64_t npix, int C,
+                          mau_stream_t stream);
+int mau_bn_bwd_rows(int64_t npix);
+
+/* ---- MaxPool2d(2,2) (src/model.py:57,218) -------------------------------- */
+int mau_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int N, int H, int W, int C,
+                       mau_stream_t stream);
+/* dx (N,H,W) = scatter of dy (N,H/2,W/2) to the first maximum of each window; rest zero. */
+int mau_maxpool2x2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int dtype,
+                       int N, int H, int W, int C, mau_stream_t stream);
+
+/* ---- bilinear resize, align_corners=True (src/model.py:111-121,219,243-246) ---- */
+/* dst[..., choff:choff+C] = resize(src (N,h,w,C)) to (H,W); other channels of dst untouched. */
+int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst, int lddst, int choff,
+                            int dtype, int N, int H, int W, int C, mau_stream_t stream);
+/* dsrc (N,h,w,C) = adjoint of the above applied to ddst[..., choff:choff+C] (gather form, no atomics). */
+int mau_resize_bilinear_bwd(const void* ddst, int ldddst, int choff, int H, int W, void* dsrc, int lddsrc,
+                            int dtype, int N, int h, int w, int C, mau_stream_t stream);
+/* dst[..., choff:choff+C] = src[..., :C]  (channel concat building block, src/model.py:279-282);
+ * also zero-fills dst channels [choff+C, zero_to) when zero_to > choff+C. */
+int mau_copy_channels(const void* src, int ldsrc, void* dst, int lddst, int choff, int zero_to, int dtype,
+                      int64_t npix, int C, mau_stream_t stream);
+/* dst[n, :, choff:choff+E] = emb[n] broadcast over the HW pixels (materialised form of
+ * fuse_embeddings, src/model.py:248-259; the fused form is the `emb` source of mau_conv3x3_fwd). */
+int mau_bcast_fill(const float* emb, void* dst, int lddst, int choff, int zero_to, int dtype, int N, int HW,
+                   int E, mau_stream_t stream);
+/* demb (N,E) fp32 = sum over pixels of dx[..., choff:choff+E]  (adjoint of the embedding broadcast). */
+int mau_bcast_bwd(const void* dx, int lddx, int choff, float* demb, int dtype, int N, int HW, int E,
+                  mau_stream_t stream);
+
+/* ---- head: 1x1 conv + tanh on channel 0 (src/model.py:241,284-292) -------- */
+/* out (N,Co,H,W) fp32 NCHW; tanh on channel 0 iff tanh0 != 0 (the reference does so iff Co == 2). */
+int mau_head_fwd(const void* a, int lda, const float* w, const float* b, float* out, int tanh0, int dtype,
+                 int N, int HW, int C, int Co, mau_stream_t stream);
+/* da NHWC-ld = W^T dz with dz = dout * (1 - out^2 on the tanh channel); slab
+ * [mau_head_bwd_rows][mau_head_bwd_rowlen] holds per-block partial sums: for output channel o,
+ * row[o*(C8+8) + c] = partial dW[o][c] and row[o*(C8+8) + C8] = partial db[o]  (C8 = roundup(C,8)). */
+int mau_head_bwd(const void* a, int lda, const float* w, const float* out, const float* dout, void* da,
+                 int ldda, float* slab, int tanh0, int dtype, int N, int HW, int C, int Co,
+                 mau_stream_t stream);
+int mau_head_bwd_rows(int N, int HW);
+int mau_head_bwd_rowlen(int C, int Co);
+
+/* ---- MetadataEncoder: Linear(F,32) -> ReLU -> Linear(32,D) (src/model.py:38-48) ---- */
+int mau_meta_mlp_fwd(const float* md, const float* w0, const float* b0, const float* w2, const float* b2,
+                     float* hidden, float* emb, int N, int F, int Hd, int D, mau_stream_t stream);
+/* dhidden_ws: fp32 workspace (N,Hd). */
+int mau_meta_mlp_bwd(const float* md, const float* w0, const float* w2, const float* hidden,
+                     const float* demb, float* dw0, float* db0, float* dw2, float* db2, float* dhidden_ws,
+                     int N, int F, int Hd, int D, mau_stream_t stream);
+
+/* ---- loss: F.mse_loss (src/utils/losses.py:27-39) -------------------------- */
+/* loss[0] = mean((out-tgt)^2) (fp64 accumulation, fixed order); dout (optional) = 2*(out-tgt)/n;
+ * partial: fp64 workspace of mau_mse_blocks(n) elements. */
+int mau_mse_blocks(int64_t n);
+int mau_mse_fwd_bwd(const float* out, const float* tgt, double* partial, float* loss, float* dout, int64_t n,
+                    mau_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAU_HIP_H */

@@ -1,0 +1,12 @@
+"""MI355X-native (gfx950) implementation of the Metadata-Augmented U-Net hot path.
+
+Importable as ``mau_amd`` through the alias module at the repository root (the directory name
+contains hyphens).  Importing loads ``libmau_hip.so`` and fails loudly when it is missing.
+"""
+from . import _lib                      # noqa: F401  (raises if the HIP library is absent)
+from .model import (MetadataEncoder, TemporalEncoder, UrbanPredictor, UrbanPredictor_unet,  # noqa: F401
+                    UrbanPredictor_unetpp, VGGBlock)
+from .losses import compute_loss_mse   # noqa: F401
+
+__all__ = ["UrbanPredictor", "UrbanPredictor_unet", "UrbanPredictor_unetpp", "VGGBlock", "MetadataEncoder",
+           "TemporalEncoder", "compute_loss_mse"]

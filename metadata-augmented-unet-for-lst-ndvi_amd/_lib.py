@@ -1,0 +1,93 @@
+"""ctypes binding of ``libmau_hip.so`` (C ABI declared in ``include/mau_hip.h``).
+
+The library is the product: there is NO fallback.  If the shared object is
+missing or does not export every symbol of the header, importing this module
+raises; if a call returns non-zero, ``MauError`` carries ``mau_last_error()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmau_hip.so")
+
+MAU_F32 = 0
+MAU_BF16 = 1
+
+_p, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/mau_hip.h one to one
+PROTOTYPES = {
+    "mau_abi_version": (_i, []),
+    "mau_last_error": (C.c_char_p, []),
+    "mau_device_check": (_i, []),
+    "mau_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_conv3x3_kc": (_i, [_i]),
+    "mau_conv3x3_packed_elems": (_sz, [_i, _i, _i]),
+    "mau_conv3x3_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "mau_conv3x3_num_pixel_tiles": (_i, [_i, _i, _i]),
+    "mau_conv3x3_fwd": (_i, [_p, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "mau_conv3x3_wgrad": (_i, [_p, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "mau_conv3x3_wgrad_acc_elems": (_sz, [_i, _i]),
+    "mau_conv3x3_unpack_wgrad": (_i, [_p, _p, _i, _i, _p]),
+    "mau_reduce_rows_f64": (_i, [_p, _i, _i, _i, _p, _p]),
+    "mau_reduce_rows_f32": (_i, [_p, _i, _i, _i, _p, _p]),
+    "mau_bn_finalize_train": (_i, [_p, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
+    "mau_bn_coeffs_eval": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p]),
+    "mau_bn_relu_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _i64, _i, _p]),
+    "mau_bn_relu_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
+    "mau_bn_relu_bwd_apply": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _d, _p, _i, _i, _i64, _i, _p]),
+    "mau_bn_bwd_rows": (_i, [_i64]),
+    "mau_maxpool2x2_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_maxpool2x2_bwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_resize_bilinear_fwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_resize_bilinear_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_copy_channels": (_i, [_p, _i, _p, _i, _i, _i, _i, _i64, _i, _p]),
+    "mau_bcast_fill": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_bcast_bwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "mau_head_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_head_bwd": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_head_bwd_rows": (_i, [_i, _i]),
+    "mau_head_bwd_rowlen": (_i, [_i, _i]),
+    "mau_meta_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mau_meta_mlp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mau_mse_blocks": (_i, [_i64]),
+    "mau_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
+}
+
+
+class MauError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MI355X-native HIP library has not been built "
+            f"(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C {os.path.join(_HERE, 'csrc')}`). "
+            "There is no CPU or PyTorch fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [n for n in PROTOTYPES if not hasattr(lib, n)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} does not export {missing}; rebuild it")
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = lib.mau_last_error()
+        raise MauError(f"libmau_hip {what} failed (status {status}): {msg.decode() if msg else '?'}")
+
+
+def call(name: str, *args):
+    """Call an int-status entry point and raise on error."""
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,250 @@
+// bn.hip -- train/eval BatchNorm2d + ReLU on NHWC-ld activations (reference src/model.py:13,15,16).
+//
+// Forward, train mode:  conv epilogue -> per-tile partial sums (slab)  -> reduce_rows (fp64)
+//                       -> [RCCL all-reduce when data parallel] -> bn_finalize_train -> bn_relu_apply
+// Backward:             bn_relu_bwd_reduce (partials) -> reduce_rows -> [all-reduce] -> bn_relu_bwd_apply
+// All reductions are slab + fixed-order second stage: bitwise reproducible, no float atomics.
+// All of these kernels are HBM-streaming: 16-byte (bf16) / 32-byte (f32) vectors per lane.
+#include "mau_common.h"
+
+namespace mau {
+
+// ---- column sums of a row-major fp32 slab [rows][ldrow] -> out[M], accumulated in fp64 ----
+template <typename OutT>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ slab, int rows, int M, int ldrow,
+                                                          OutT* __restrict__ out) {
+  // block = 64 columns x 4 row-lanes; each wave reads 64 consecutive columns of one row (256 B)
+  __shared__ double part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  double s = 0.0;
+  if (col < M)
+    for (int r = rl; r < rows; r += 4) s += (double)slab[(size_t)r * ldrow + col];
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && col < M) out[col] = (OutT)(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ void bn_finalize_train_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                         int64_t* nbt, float momentum, float eps, float* __restrict__ scale,
+                                         float* __restrict__ shift, float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                         int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  const double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;     // biased variance (normalisation)
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_o[c] = (float)mean;
+  invstd_o[c] = invstd;
+  if (rmean) {
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_coeffs_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
+                                      float* __restrict__ invstd_o, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(rvar[c] + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - rmean[c] * sc;
+  if (mean_o) mean_o[c] = rmean[c];
+  if (invstd_o) invstd_o[c] = is;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, T* __restrict__ a, int lda,
+                                                            int64_t npix, int C, int C8) {
+  const int nv = C8 >> 3;
+  const int64_t total = npix * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx / nv;
+    const int c = (int)(idx % nv) * 8;
+    F8 v = load8<T>(y + pix * ldy + c);
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cc = c + j;
+      float r = 0.f;
+      if (cc < C) r = fmaxf(fmaf(v.v[j], scale[cc], shift[cc]), 0.f);
+      o.v[j] = r;
+    }
+    store8<T>(a + pix * lda + c, o);
+  }
+}
+
+// Backward pass 1: block (64 channels x PIXB pixel slots); partial sums of dz and dz*xhat.
+constexpr int BWD_PIX_PER_BLOCK = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ y,
+                                                                 int ldy, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, float* __restrict__ slab,
+                                                                 int ldslab, int64_t npix, int C) {
+  // threads: 8 channel-vectors (64 channels) x 32 pixel slots
+  __shared__ float red[2][32][64 + 1];
+  const int cv = threadIdx.x & 7, ps = threadIdx.x >> 3;
+  const int c0 = blockIdx.y * 64 + cv * 8;
+  const int64_t p0 = (int64_t)blockIdx.x * BWD_PIX_PER_BLOCK;
+  const int64_t p1 = p0 + BWD_PIX_PER_BLOCK < npix ? p0 + BWD_PIX_PER_BLOCK : npix;
+  float s1[8], s2[8], sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = s2[j] = 0.f;
+    const int cc = c0 + j;
+    const bool ok = cc < C;
+    sc[j] = ok ? scale[cc] : 0.f;
+    sh[j] = ok ? shift[cc] : 0.f;
+    mu[j] = ok ? mean[cc] : 0.f;
+    is[j] = ok ? invstd[cc] : 0.f;
+  }
+  if (c0 < C) {
+    for (int64_t p = p0 + ps; p < p1; p += 32) {
+      const F8 g = load8<T>(da + p * ldda + c0);
+      const F8 v = load8<T>(y + p * ldy + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float act = fmaf(v.v[j], sc[j], sh[j]);
+        const float dz = act > 0.f ? g.v[j] : 0.f;
+        s1[j] += dz;
+        s2[j] += dz * ((v.v[j] - mu[j]) * is[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[0][ps][cv * 8 + j] = s1[j];
+    red[1][ps][cv * 8 + j] = s2[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) s += red[which][r][c];
+    const int cc = blockIdx.y * 64 + c;
+    if (cc < ldslab) slab[((size_t)blockIdx.x * 2 + which) * ldslab + cc] = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ y,
+                                                                int ldy, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const double* __restrict__ sums,
+                                                                double inv_count, T* __restrict__ dy, int lddy, int64_t npix,
+                                                                int C, int C8) {
+  const int nv = C8 >> 3;
+  const int64_t total = npix * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx / nv;
+    const int c = (int)(idx % nv) * 8;
+    const F8 g = load8<T>(da + pix * ldda + c);
+    const F8 v = load8<T>(y + pix * ldy + c);
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cc = c + j;
+      float r = 0.f;
+      if (cc < C) {
+        const float sc = scale[cc];
+        const float act = fmaf(v.v[j], sc, shift[cc]);
+        const float dz = act > 0.f ? g.v[j] : 0.f;
+        const float xhat = (v.v[j] - mean[cc]) * invstd[cc];
+        const float m1 = (float)(sums[cc] * inv_count), m2 = (float)(sums[C + cc] * inv_count);
+        r = sc * (dz - m1 - xhat * m2);
+      }
+      o.v[j] = r;
+    }
+    store8<T>(dy + pix * lddy + c, o);
+  }
+}
+
+}  // namespace mau
+
+using namespace mau;
+
+extern "C" {
+
+int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, mau_stream_t stream) {
+  MAU_REQUIRE(slab && sums && rows > 0 && M > 0 && ldrow >= M, "reduce_rows: bad arguments");
+  hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(ceil_div(M, 64)), dim3(256), 0, (hipStream_t)stream, slab, rows, M, ldrow, sums);
+  return check_launch("reduce_rows_kernel<double>");
+}
+
+int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, mau_stream_t stream) {
+  MAU_REQUIRE(slab && out && rows > 0 && M > 0 && ldrow >= M, "reduce_rows: bad arguments");
+  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(ceil_div(M, 64)), dim3(256), 0, (hipStream_t)stream, slab, rows, M, ldrow, out);
+  return check_launch("reduce_rows_kernel<float>");
+}
+
+int mau_bn_finalize_train(const double* sums, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                          float* scale, float* shift, float* mean, float* invstd, int C, mau_stream_t stream) {
+  MAU_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0, "bn_finalize_train: bad arguments");
+  MAU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_train: running_mean/var must come together");
+  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
+                     beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd, C);
+  return check_launch("bn_finalize_train_kernel");
+}
+
+int mau_bn_coeffs_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* scale, float* shift, float* mean, float* invstd, int C, mau_stream_t stream) {
+  MAU_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_coeffs_eval: bad arguments");
+  hipLaunchKernelGGL(bn_coeffs_eval_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, scale, shift, mean, invstd, C);
+  return check_launch("bn_coeffs_eval_kernel");
+}
+
+int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift, void* a, int lda, int dtype,
+                      int64_t npix, int C, mau_stream_t stream) {
+  MAU_REQUIRE(y && a && scale && shift && npix > 0 && C > 0, "bn_relu_apply: bad arguments");
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(ldy % 8 == 0 && lda % 8 == 0 && ldy >= C8 && lda >= C8, "bn_relu_apply: bad ld");
+  const int grid = stream_grid(npix * (C8 / 8), 256);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)y, ldy, scale, shift, (T*)a, lda, npix, C, C8));
+  return check_launch("bn_relu_apply_kernel");
+}
+
+int mau_bn_bwd_rows(int64_t npix) { return ceil_div(npix, BWD_PIX_PER_BLOCK); }
+
+int mau_bn_relu_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, float* slab, int ldslab, int dtype, int64_t npix,
+                           int C, mau_stream_t stream) {
+  MAU_REQUIRE(da && y && scale && shift && mean && invstd && slab && npix > 0 && C > 0, "bn_relu_bwd_reduce: bad arguments");
+  MAU_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && ldslab >= C, "bn_relu_bwd_reduce: bad ld");
+  dim3 grid(mau_bn_bwd_rows(npix), ceil_div(C, 64));
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, slab,
+                                               ldslab, npix, C));
+  return check_launch("bn_relu_bwd_reduce_kernel");
+}
+
+int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const double* sums, double count, void* dy, int lddy,
+                          int dtype, int64_t npix, int C, mau_stream_t stream) {
+  MAU_REQUIRE(da && y && dy && sums && npix > 0 && C > 0 && count > 0, "bn_relu_bwd_apply: bad arguments");
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && lddy >= C8, "bn_relu_bwd_apply: bad ld");
+  const int grid = stream_grid(npix * (C8 / 8), 256);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, sums,
+                                               1.0 / count, (T*)dy, lddy, npix, C, C8));
+  return check_launch("bn_relu_bwd_apply_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,560 @@
+// conv3x3.hip -- 3x3 / stride 1 / pad 1 convolution on NHWC-ld activations as an im2col-free
+// implicit GEMM on the gfx950 matrix cores.
+//
+//   forward / data-gradient :  M = pixels (8x16 spatial tile per workgroup), N = 64 output
+//                              channels, K = 9 taps x KC input channels per chunk.
+//   weight-gradient         :  M = 64 output channels, N = 64 input channels (x 9 taps kept in
+//                              accumulators), K = pixels.
+//
+// One template serves both arithmetic types:
+//   float : v_mfma_f32_32x32x2_f32   (exact fp32 FMA chain -- the parity mode)
+//   bf16  : v_mfma_f32_32x32x16_bf16 (fp32 accumulation   -- the throughput mode)
+// The input halo tile ((8+2)x(16+2) pixels x KC channels) is staged ONCE per channel chunk in LDS
+// and re-read for the 9 taps at shifted pixel offsets; nothing is ever expanded to im2col form.
+//
+// Replaces nn.Conv2d(cin, cout, 3, padding=1) of VGGBlock (reference src/model.py:12,14), the
+// first half of train-mode BatchNorm2d (:13,15: per-channel sum / sum of squares, fused into the
+// epilogue) and fuse_embeddings (:248-259: the broadcast embedding is a second, spatially
+// constant K-source of the loader and is never materialised).
+#include "mau_common.h"
+
+namespace mau {
+
+constexpr int TH = 8, TW = 16;               // spatial tile (pixels)
+constexpr int HW_ = TW + 2, HH_ = TH + 2;    // halo tile
+constexpr int HALO = HW_ * HH_;              // 180 pixels
+constexpr int BN = 64;                       // output-channel tile
+constexpr int NT = 256;                      // threads per workgroup (4 waves)
+
+template <typename T>
+struct Cfg;
+template <>
+struct Cfg<float> {
+  static constexpr int KC = 16;    // channels per K-chunk
+  static constexpr int KPL = 1;    // k elements per lane per MFMA operand
+  static constexpr int KCP = 17;   // padded LDS row (elements): conflict-free ds_read_b32
+  static constexpr int VEC = 4;    // elements per 16-byte global vector
+  static constexpr int WP = 64;    // wgrad LDS row (elements)
+  using frag = float;
+};
+template <>
+struct Cfg<bf16> {
+  static constexpr int KC = 32;
+  static constexpr int KPL = 8;
+  static constexpr int KCP = 40;   // 80-byte rows: 16 consecutive pixels hit 16 distinct 16-B slots
+  static constexpr int VEC = 8;
+  static constexpr int WP = 72;    // 144-byte rows for the transposed reads
+  using frag = bf16x8;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ typename Cfg<T>::frag lds_frag(const T* p) {
+  return *reinterpret_cast<const typename Cfg<T>::frag*>(p);
+}
+
+// 16 bytes of T moved global -> register -> LDS
+template <typename T>
+__device__ __forceinline__ void lds_put(T* dst, const uint4& v);
+template <>
+__device__ __forceinline__ void lds_put<bf16>(bf16* dst, const uint4& v) {
+  *reinterpret_cast<uint4*>(dst) = v;   // 16-byte aligned by construction
+}
+template <>
+__device__ __forceinline__ void lds_put<float>(float* dst, const uint4& v) {
+  // rows are padded to 17 floats -> scalar stores
+  dst[0] = __uint_as_float(v.x);
+  dst[1] = __uint_as_float(v.y);
+  dst[2] = __uint_as_float(v.z);
+  dst[3] = __uint_as_float(v.w);
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack_emb(const float* e);
+template <>
+__device__ __forceinline__ uint4 pack_emb<float>(const float* e) {
+  return *reinterpret_cast<const uint4*>(e);
+}
+template <>
+__device__ __forceinline__ uint4 pack_emb<bf16>(const float* e) {
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(e), hi = *reinterpret_cast<const f32x4*>(e + 4);
+  bf16x8 t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    t[i] = (bf16)lo[i];
+    t[4 + i] = (bf16)hi[i];
+  }
+  return __builtin_bit_cast(uint4, t);
+}
+
+struct ConvP {
+  const void* x;
+  int ldx, C0;
+  const float* emb;
+  int E;
+  const void* w;
+  const float* bias;
+  void* y;
+  int ldy, Cout, CoutPad;
+  float* slab;
+  int N, H, W, tilesX, tilesY, nChunks;
+};
+
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+template <typename T>
+__global__ __launch_bounds__(NT) void conv3x3_igemm_kernel(ConvP p) {
+  using C = Cfg<T>;
+  constexpr int KC = C::KC, KPL = C::KPL, KCP = C::KCP, VEC = C::VEC;
+  constexpr int KSTEP = 2 * KPL;             // k covered by one MFMA
+  constexpr int VPP = KC / VEC;              // 16-byte vectors per pixel / per weight row
+  constexpr int HALO_V = HALO * VPP;         // vectors in the halo tile
+  constexpr int HALO_PT = (HALO_V + NT - 1) / NT;
+  constexpr int W_V = 9 * BN * VPP;          // vectors in the weight slab
+  constexpr int W_PT = W_V / NT;
+  static_assert(W_V % NT == 0, "weight slab must divide evenly");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* lds_h = reinterpret_cast<T*>(smem);                  // [HALO][KCP]
+  T* lds_w = lds_h + HALO * KCP;                          // [9][BN][KCP]
+  // (HALO*KCP*sizeof(T) is a multiple of 16 for both configurations)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int i32 = lane & 31, h = lane >> 5;
+
+  int tile = blockIdx.x;
+  const int txi = tile % p.tilesX;
+  tile /= p.tilesX;
+  const int tyi = tile % p.tilesY;
+  const int n = tile / p.tilesY;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int co0 = blockIdx.y * BN;
+
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+
+  // ---- per-thread source descriptors of the halo vectors (constant over chunks) ----
+  size_t h_off[HALO_PT];
+  int h_dst[HALO_PT];
+  int h_kv[HALO_PT];
+  bool h_inb[HALO_PT];
+#pragma unroll
+  for (int j = 0; j < HALO_PT; ++j) {
+    const int v = tid + j * NT;
+    const int hp = v / VPP, kv = v % VPP;
+    const int hy = hp / HW_, hx = hp % HW_;
+    const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+    h_inb[j] = (v < HALO_V) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    h_off[j] = ((size_t)(n * p.H + (h_inb[j] ? gy : 0)) * p.W + (h_inb[j] ? gx : 0)) * (size_t)p.ldx;
+    h_dst[j] = (v < HALO_V) ? hp * KCP + kv * VEC : -1;
+    h_kv[j] = kv * VEC;
+  }
+
+  // per-thread weight vectors: v = tid + j*NT -> (tap = j*NT/(BN*VPP) + ..., row, kv); with
+  // BN*VPP == NT each j is exactly one tap and (row, kv) depend on tid only.
+  static_assert(BN * VPP == NT, "one tap per prefetch slot");
+  const int w_row = tid / VPP, w_kv = (tid % VPP) * VEC;
+  uint4 hv0 = make_uint4(0, 0, 0, 0), hv1 = hv0, hv2 = hv0;
+  static_assert(HALO_PT == 3, "three halo vectors per thread");
+  uint4 wv0, wv1, wv2, wv3, wv4, wv5, wv6, wv7, wv8;
+  static_assert(W_PT == 9, "nine weight vectors per thread");
+
+#define MAU_HALO_LOAD(J, DST)                                                          \
+  {                                                                                    \
+    const int c = c0 + h_kv[J];                                                        \
+    uint4 r = make_uint4(0, 0, 0, 0);                                                  \
+    if (h_inb[J]) {                                                                    \
+      if (c < p.C0 || (p.E == 0 && c < p.ldx)) {                                       \
+        r = *reinterpret_cast<const uint4*>(xg + h_off[J] + c);                        \
+      } else if (c < p.C0 + p.E) {                                                     \
+        r = pack_emb<T>(p.emb + (size_t)n * p.E + (c - p.C0));                         \
+      }                                                                                \
+    }                                                                                  \
+    DST = r;                                                                           \
+  }
+#define MAU_W_LOAD(J, DST) \
+  DST = *reinterpret_cast<const uint4*>(wsrc + ((size_t)(J)*p.CoutPad + co0 + w_row) * KC + w_kv);
+#define MAU_ISSUE(CHUNK)                                                 \
+  {                                                                      \
+    const int c0 = (CHUNK)*KC;                                           \
+    MAU_HALO_LOAD(0, hv0) MAU_HALO_LOAD(1, hv1) MAU_HALO_LOAD(2, hv2)    \
+    const T* wsrc = wg + (size_t)(CHUNK)*9 * p.CoutPad * KC;             \
+    MAU_W_LOAD(0, wv0) MAU_W_LOAD(1, wv1) MAU_W_LOAD(2, wv2)             \
+    MAU_W_LOAD(3, wv3) MAU_W_LOAD(4, wv4) MAU_W_LOAD(5, wv5)             \
+    MAU_W_LOAD(6, wv6) MAU_W_LOAD(7, wv7) MAU_W_LOAD(8, wv8)             \
+  }
+#define MAU_W_PUT(J, SRC) lds_put<T>(lds_w + ((J)*BN + w_row) * KCP + w_kv, SRC);
+#define MAU_COMMIT()                                              \
+  {                                                               \
+    if (h_dst[0] >= 0) lds_put<T>(lds_h + h_dst[0], hv0);         \
+    if (h_dst[1] >= 0) lds_put<T>(lds_h + h_dst[1], hv1);         \
+    if (h_dst[2] >= 0) lds_put<T>(lds_h + h_dst[2], hv2);         \
+    MAU_W_PUT(0, wv0) MAU_W_PUT(1, wv1) MAU_W_PUT(2, wv2)         \
+    MAU_W_PUT(3, wv3) MAU_W_PUT(4, wv4) MAU_W_PUT(5, wv5)         \
+    MAU_W_PUT(6, wv6) MAU_W_PUT(7, wv7) MAU_W_PUT(8, wv8)         \
+  }
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc0[r] = 0.f;
+    acc1[r] = 0.f;
+  }
+
+  // wave (wm, wn): pixels rows [wm*4, wm*4+4) of the tile x output channels [wn*32, wn*32+32)
+  const T* hb = lds_h + ((wm * 4 + (i32 >> 4)) * HW_ + (i32 & 15)) * KCP + h * KPL;
+  const T* wb = lds_w + (wn * 32 + i32) * KCP + h * KPL;
+
+  MAU_ISSUE(0)
+  for (int chunk = 0; chunk < p.nChunks; ++chunk) {
+    __syncthreads();
+    MAU_COMMIT()
+    __syncthreads();
+    if (chunk + 1 < p.nChunks) MAU_ISSUE(chunk + 1)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = ((tap / 3) * HW_ + (tap % 3)) * KCP;
+#pragma unroll
+      for (int ks = 0; ks < KC / KSTEP; ++ks) {
+        const auto a0 = lds_frag<T>(hb + toff + ks * KSTEP);
+        const auto a1 = lds_frag<T>(hb + 2 * HW_ * KCP + toff + ks * KSTEP);
+        const auto b = lds_frag<T>(wb + tap * BN * KCP + ks * KSTEP);
+        acc0 = mfma32(a0, b, acc0);
+        acc1 = mfma32(a1, b, acc1);
+      }
+    }
+  }
+
+  // ---- epilogue: bias, BatchNorm partial statistics, store ----
+  const int co = co0 + wn * 32 + i32;
+  const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int prow = acc_row(r, h);
+      const int ty = wm * 4 + mt * 2 + (prow >> 4), tx = prow & 15;
+      const int gy = ty0 + ty, gx = tx0 + tx;
+      const bool valid = gy < p.H && gx < p.W;
+      const float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
+      if (valid) {
+        s += v;
+        q += v * v;
+        if (co < p.ldy) yg[((size_t)(n * p.H + gy) * p.W + gx) * p.ldy + co] = (T)v;
+      }
+    }
+  }
+  if (p.slab != nullptr) {
+    s += __shfl_xor(s, 32);
+    q += __shfl_xor(q, 32);
+    __syncthreads();                                  // everyone is done with the LDS tiles
+    float* red = reinterpret_cast<float*>(smem);      // [2 wm][2 which][64]
+    if (h == 0) {
+      red[(wm * 2 + 0) * 64 + wn * 32 + i32] = s;
+      red[(wm * 2 + 1) * 64 + wn * 32 + i32] = q;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      p.slab[((size_t)blockIdx.x * 2 + which) * p.CoutPad + co0 + c] = red[(0 * 2 + which) * 64 + c] + red[(1 * 2 + which) * 64 + c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------
+struct WgradP {
+  const void* x;
+  int ldx, C0;
+  const float* emb;
+  int E;
+  const void* dy;
+  int lddy, Cout, CoutPad, Cin, CinPad;
+  float* acc;
+  int N, H, W, tilesX, tilesY, nTiles;
+};
+
+template <typename T>
+struct WFrag;
+template <>
+struct WFrag<float> {
+  // A[i][k]: lane (i = l&31, k = l>>5) -- one element, rows of the LDS image are pixels (k)
+  static __device__ __forceinline__ float load(const float* img, int pix0, int col0, int lane) {
+    return img[(pix0 + (lane >> 5)) * Cfg<float>::WP + col0 + (lane & 31)];
+  }
+  static constexpr int KSTEP = 2;
+};
+template <>
+struct WFrag<bf16> {
+  // 32x32x16 operand from a [pixel][channel] LDS image with two transposed 64-bit reads:
+  // lane (r = l&31, h = l>>5) needs channel r at pixels pix0 + 8h + 0..7.
+  static __device__ __forceinline__ bf16x8 load(const bf16* img, int pix0, int col0, int lane) {
+    const int q = (lane & 15) >> 2, pp = lane & 3, g = (lane >> 4) & 1, h = lane >> 5;
+    const bf16* a = img + (pix0 + 8 * h + q) * Cfg<bf16>::WP + col0 + 16 * g + 4 * pp;
+    typedef __attribute__((address_space(3))) s16x4* lptr;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 4 * Cfg<bf16>::WP));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+  }
+  static constexpr int KSTEP = 16;
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT) void conv3x3_wgrad_kernel(WgradP p) {
+  using C = Cfg<T>;
+  constexpr int VEC = C::VEC, WP = C::WP;
+  constexpr int VPR = 64 / VEC;                 // 16-byte vectors per 64-channel row
+  constexpr int DY_V = TH * TW * VPR, X_V = HALO * VPR;
+  constexpr int KSTEP = WFrag<T>::KSTEP;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* dyt = reinterpret_cast<T*>(smem);          // [128][WP]
+  T* xh = dyt + TH * TW * WP;                   // [180][WP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave & 1, wci = wave >> 1;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int tile = blockIdx.x; tile < p.nTiles; tile += gridDim.x) {
+    int tt = tile;
+    const int txi = tt % p.tilesX;
+    tt /= p.tilesX;
+    const int tyi = tt % p.tilesY;
+    const int n = tt / p.tilesY;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+
+    __syncthreads();
+    for (int v = tid; v < DY_V; v += NT) {
+      const int pix = v / VPR, kv = (v % VPR) * VEC;
+      const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
+      const int c = co0 + kv;
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (gy < p.H && gx < p.W && c < p.lddy)
+        u = *reinterpret_cast<const uint4*>(dyg + ((size_t)(n * p.H + gy) * p.W + gx) * p.lddy + c);
+      *reinterpret_cast<uint4*>(dyt + pix * WP + kv) = u;
+    }
+    for (int v = tid; v < X_V; v += NT) {
+      const int hp = v / VPR, kv = (v % VPR) * VEC;
+      const int gy = ty0 + hp / HW_ - 1, gx = tx0 + hp % HW_ - 1;
+      const int c = ci0 + kv;
+      uint4 r = make_uint4(0, 0, 0, 0);
+      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+        if (c < p.C0 || (p.E == 0 && c < p.ldx))
+          r = *reinterpret_cast<const uint4*>(xg + ((size_t)(n * p.H + gy) * p.W + gx) * p.ldx + c);
+        else if (c < p.C0 + p.E)
+          r = pack_emb<T>(p.emb + (size_t)n * p.E + (c - p.C0));
+      }
+      *reinterpret_cast<uint4*>(xh + hp * WP + kv) = r;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int trow = 0; trow < TH; ++trow) {
+#pragma unroll
+      for (int k0 = 0; k0 < TW; k0 += KSTEP) {
+        const auto a = WFrag<T>::load(dyt, trow * TW + k0, wco * 32, lane);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const auto b = WFrag<T>::load(xh, (trow + tap / 3) * HW_ + k0 + tap % 3, wci * 32, lane);
+          acc[tap] = mfma32(a, b, acc[tap]);
+        }
+      }
+    }
+  }
+
+  const int h = lane >> 5;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + acc_row(r, h);
+      const int ci = ci0 + wci * 32 + (lane & 31);
+      atomicAdd(p.acc + ((size_t)tap * p.CoutPad + co) * p.CinPad + ci, acc[tap][r]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing / gradient unpacking
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
+                                    int Cout, int Cin) {
+  constexpr int KC = Cfg<T>::KC;
+  const int CoutPad = (Cout + 63) / 64 * 64, CinPad = (Cin + 63) / 64 * 64;
+  const int nChF = (Cin + KC - 1) / KC, nChD = (Cout + KC - 1) / KC;
+  const size_t nF = (size_t)nChF * 9 * CoutPad * KC, nD = (size_t)nChD * 9 * CinPad * KC;
+  const size_t total = nF + (wd ? nD : 0);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    if (idx < nF) {
+      size_t t = idx;
+      const int kc = t % KC;
+      t /= KC;
+      const int co = t % CoutPad;
+      t /= CoutPad;
+      const int tap = t % 9;
+      const int ci = (int)(t / 9) * KC + kc;
+      float v = 0.f;
+      if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 9 + tap];
+      wf[idx] = (T)v;
+    } else {
+      size_t t = idx - nF;
+      const int kc = t % KC;
+      t /= KC;
+      const int ci = t % CinPad;
+      t /= CinPad;
+      const int tap = t % 9;
+      const int co = (int)(t / 9) * KC + kc;
+      float v = 0.f;
+      if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];
+      wd[idx - nF] = (T)v;
+    }
+  }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ acc, float* __restrict__ dw, int Cout, int Cin,
+                                    int CoutPad, int CinPad) {
+  const size_t total = (size_t)Cout * Cin * 9;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t t = idx;
+    const int tap = t % 9;
+    t /= 9;
+    const int ci = t % Cin;
+    const int co = (int)(t / Cin);
+    dw[idx] = acc[((size_t)tap * CoutPad + co) * CinPad + ci];
+  }
+}
+
+template <typename T>
+static size_t conv_lds_bytes() {
+  return (size_t)(HALO + 9 * BN) * Cfg<T>::KCP * sizeof(T);
+}
+template <typename T>
+static size_t wgrad_lds_bytes() {
+  return (size_t)(TH * TW + HALO) * Cfg<T>::WP * sizeof(T);
+}
+
+template <typename T>
+static int launch_conv(const ConvP& p, hipStream_t st) {
+  static bool attr_set = false;
+  const size_t lds = conv_lds_bytes<T>();
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_kernel<T>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(p.N * p.tilesX * p.tilesY, p.CoutPad / BN);
+  hipLaunchKernelGGL(conv3x3_igemm_kernel<T>, grid, dim3(NT), lds, st, p);
+  return check_launch("conv3x3_igemm_kernel");
+}
+
+template <typename T>
+static int launch_wgrad(const WgradP& p, hipStream_t st) {
+  static bool attr_set = false;
+  const size_t lds = wgrad_lds_bytes<T>();
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<T>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int tilesOut = (p.CoutPad / 64) * (p.CinPad / 64);
+  int splits = (256 * 4 + tilesOut - 1) / tilesOut;     // aim at ~4 workgroups per CU
+  if (splits > p.nTiles) splits = p.nTiles;
+  if (splits < 1) splits = 1;
+  dim3 grid(splits, p.CoutPad / 64, p.CinPad / 64);
+  hipLaunchKernelGGL(conv3x3_wgrad_kernel<T>, grid, dim3(NT), lds, st, p);
+  return check_launch("conv3x3_wgrad_kernel");
+}
+
+}  // namespace mau
+
+using namespace mau;
+
+extern "C" {
+
+int mau_conv3x3_kc(int dtype) { return dtype == MAU_F32 ? Cfg<float>::KC : Cfg<bf16>::KC; }
+
+size_t mau_conv3x3_packed_elems(int dtype, int nout, int nin) {
+  const int kc = mau_conv3x3_kc(dtype);
+  return (size_t)ceil_div(nin, kc) * 9 * round_up(nout, 64) * kc;
+}
+
+int mau_conv3x3_pack_weights(const float* w, void* wf, void* wd, int dtype, int Cout, int Cin,
+                             mau_stream_t stream) {
+  MAU_REQUIRE(w && wf && Cout > 0 && Cin > 0, "pack_weights: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = mau_conv3x3_packed_elems(dtype, Cout, Cin) + (wd ? mau_conv3x3_packed_elems(dtype, Cin, Cout) : 0);
+  const int grid = stream_grid((int64_t)total, 256);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(grid), dim3(256), 0, st, w, (T*)wf, (T*)wd, Cout, Cin));
+  return check_launch("pack_weights_kernel");
+}
+
+int mau_conv3x3_num_pixel_tiles(int N, int H, int W) { return N * ceil_div(H, TH) * ceil_div(W, TW); }
+
+int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, int E, const void* wpk,
+                    const float* bias, void* y, int ldy, int Cout, float* slab, int dtype, int N, int H,
+                    int W, mau_stream_t stream) {
+  MAU_REQUIRE(x && wpk && y, "conv3x3_fwd: null pointer");
+  MAU_REQUIRE(N > 0 && H > 0 && W > 0 && C0 > 0 && Cout > 0, "conv3x3_fwd: bad shape");
+  MAU_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C0 && ldy >= Cout, "conv3x3_fwd: ld must be a multiple of 8 and >= C");
+  MAU_REQUIRE(E >= 0 && (E == 0 || (emb && E % 8 == 0 && C0 % 8 == 0)), "conv3x3_fwd: broadcast source needs E%%8==0 and C0%%8==0");
+  MAU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wpk % 16) == 0, "conv3x3_fwd: pointers must be 16-byte aligned");
+  ConvP p;
+  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.E = E; p.w = wpk; p.bias = bias; p.y = y; p.ldy = ldy;
+  p.Cout = Cout; p.CoutPad = round_up(Cout, 64); p.slab = slab; p.N = N; p.H = H; p.W = W;
+  p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
+  p.nChunks = ceil_div(C0 + E, mau_conv3x3_kc(dtype));
+  MAU_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, (hipStream_t)stream));
+}
+
+size_t mau_conv3x3_wgrad_acc_elems(int Cout, int Cin) { return (size_t)9 * round_up(Cout, 64) * round_up(Cin, 64); }
+
+int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, int E, const void* dy, int lddy,
+                      int Cout, float* acc, int dtype, int N, int H, int W, mau_stream_t stream) {
+  MAU_REQUIRE(x && dy && acc, "conv3x3_wgrad: null pointer");
+  MAU_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && ldx >= C0 && lddy >= Cout, "conv3x3_wgrad: bad ld");
+  MAU_REQUIRE(E >= 0 && (E == 0 || (emb && E % 8 == 0 && C0 % 8 == 0)), "conv3x3_wgrad: broadcast source needs E%%8==0 and C0%%8==0");
+  MAU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv3x3_wgrad: pointers must be 16-byte aligned");
+  WgradP p;
+  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.E = E; p.dy = dy; p.lddy = lddy; p.Cout = Cout;
+  p.CoutPad = round_up(Cout, 64); p.Cin = C0 + E; p.CinPad = round_up(C0 + E, 64); p.acc = acc;
+  p.N = N; p.H = H; p.W = W; p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
+  p.nTiles = N * p.tilesX * p.tilesY;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(acc, 0, mau_conv3x3_wgrad_acc_elems(Cout, C0 + E) * sizeof(float), st) != hipSuccess) {
+    set_error("conv3x3_wgrad: hipMemsetAsync failed");
+    return MAU_ERR_HIP;
+  }
+  MAU_DISPATCH_DTYPE(dtype, return launch_wgrad<T>(p, st));
+}
+
+int mau_conv3x3_unpack_wgrad(const float* acc, float* dw, int Cout, int Cin, mau_stream_t stream) {
+  MAU_REQUIRE(acc && dw && Cout > 0 && Cin > 0, "unpack_wgrad: bad arguments");
+  const int grid = stream_grid((int64_t)Cout * Cin * 9, 256);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, dw, Cout, Cin,
+                     round_up(Cout, 64), round_up(Cin, 64));
+  return check_launch("unpack_wgrad_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+// head.hip -- output head (1x1 conv + tanh on channel 0, reference src/model.py:241,284-292 and
+// :187-193), MetadataEncoder MLP (:38-48) and the MSE criterion (src/utils/losses.py:27-39).
+// The head reads NHWC-ld activations and writes the module's NCHW fp32 output directly.
+#include "mau_common.h"
+
+namespace mau {
+
+constexpr int HEAD_MAX_CO = 4;
+constexpr int HEAD_PIX_PER_BLOCK = 512;
+
+// 8 lanes per pixel: lane (pixel slot = l>>3, vec = l&7) loads 8 channels, 3 shuffle steps reduce.
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ out, int tanh0, int HW,
+                                                       int C, int Co, int64_t npix) {
+  const int sub = threadIdx.x & 7;
+  const int64_t stride = (int64_t)gridDim.x * 32;
+  const int nv = (C + 7) >> 3;
+  for (int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix + 31; pix += stride) {
+    // (loop bound rounded so that all 8 lanes of a pixel slot stay converged for the shuffles)
+    const bool live = pix < npix;
+    float acc[HEAD_MAX_CO];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_CO; ++o) acc[o] = 0.f;
+    if (live) {
+      for (int v = sub; v < nv; v += 8) {
+        const F8 x = load8<T>(a + pix * lda + v * 8);
+#pragma unroll
+        for (int o = 0; o < HEAD_MAX_CO; ++o)
+          if (o < Co) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int c = v * 8 + j;
+              if (c < C) acc[o] = fmaf(x.v[j], w[o * C + c], acc[o]);
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_CO; ++o) {
+      acc[o] += __shfl_xor(acc[o], 1);
+      acc[o] += __shfl_xor(acc[o], 2);
+      acc[o] += __shfl_xor(acc[o], 4);
+    }
+    if (live && sub < Co) {
+      float r = 0.f;
+#pragma unroll
+      for (int o = 0; o < HEAD_MAX_CO; ++o)
+        if (o == sub) r = acc[o];
+      r += b[sub];
+      if (tanh0 && sub == 0) r = tanhf(r);
+      const int64_t n = pix / HW, p = pix % HW;
+      out[((size_t)n * Co + sub) * HW + p] = r;
+    }
+  }
+}
+
+// da[p][c] = sum_o dz[o][p] * w[o][c];  partial dW[o][c] = sum_p dz[o][p]*a[p][c], db[o] = sum_p dz[o][p]
+// block: 8 channel-vector lanes x 32 pixel slots over HEAD_PIX_PER_BLOCK pixels; slab row = [Co][C8 + 8]
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
+                                                       const float* __restrict__ out, const float* __restrict__ dout,
+                                                       T* __restrict__ da, int ldda, float* __restrict__ slab, int tanh0,
+                                                       int HW, int C, int C8, int Co, int64_t npix) {
+  extern __shared__ float red[];            // [32][Co*(C8+8)] would be too big: reduce per 64-channel group instead
+  const int cv = threadIdx.x & 7, ps = threadIdx.x >> 3;
+  const int64_t p0 = (int64_t)blockIdx.x * HEAD_PIX_PER_BLOCK;
+  const int64_t p1 = p0 + HEAD_PIX_PER_BLOCK < npix ? p0 + HEAD_PIX_PER_BLOCK : npix;
+  const int rowlen = Co * (C8 + 8);
+  float* row = slab + (size_t)blockIdx.x * rowlen;
+  for (int cg = 0; cg < C8; cg += 64) {
+    const int c0 = cg + cv * 8;
+    float dwp[HEAD_MAX_CO][8], dbp[HEAD_MAX_CO];
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_CO; ++o) {
+      dbp[o] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dwp[o][j] = 0.f;
+    }
+    if (c0 < C8) {
+      for (int64_t p = p0 + ps; p < p1; p += 32) {
+        const int64_t n = p / HW, q = p % HW;
+        float dz[HEAD_MAX_CO];
+#pragma unroll
+        for (int o = 0; o < HEAD_MAX_CO; ++o) {
+          dz[o] = 0.f;
+          if (o < Co) {
+            const size_t oi = ((size_t)n * Co + o) * HW + q;
+            float g = dout[oi];
+            if (tanh0 && o == 0) {
+              const float t = out[oi];
+              g *= (1.f - t * t);
+            }
+            dz[o] = g;
+            dbp[o] += g;
+          }
+        }
+        const F8 x = load8<T>(a + p * lda + c0);
+        F8 g8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = c0 + j;
+          float s = 0.f;
+#pragma unroll
+          for (int o = 0; o < HEAD_MAX_CO; ++o)
+            if (o < Co) {
+              if (c < C) s = fmaf(dz[o], w[o * C + c], s);
+              dwp[o][j] = fmaf(dz[o], x.v[j], dwp[o][j]);
+            }
+          g8.v[j] = s;
+        }
+        store8<T>(da + p * ldda + c0, g8);
+      }
+    }
+    // reduce the 32 pixel slots through LDS: red[ps][o][64]
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_CO; ++o)
+      if (o < Co) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(ps * HEAD_MAX_CO + o) * 65 + cv * 8 + j] = dwp[o][j];
+      }
+    __syncthreads();
+    for (int t = threadIdx.x; t < Co * 64; t += 256) {
+      const int o = t >> 6, c = t & 63;
+      float s = 0.f;
+      for (int r = 0; r < 32; ++r) s += red[(r * HEAD_MAX_CO + o) * 65 + c];
+      if (cg + c < C8) row[o * (C8 + 8) + cg + c] = s;
+    }
+    if (cg == 0) {
+      __syncthreads();
+      // bias partials: only the cv == 0 lanes carry the complete per-slot sums (every cv lane of a
+      // slot saw the same pixels, so take one of them)
+      if (cv == 0) {
+#pragma unroll
+        for (int o = 0; o < HEAD_MAX_CO; ++o)
+          if (o < Co) red[ps * HEAD_MAX_CO + o] = dbp[o];
+      }
+      __syncthreads();
+      if (threadIdx.x < Co) {
+        float s = 0.f;
+        for (int r = 0; r < 32; ++r) s += red[r * HEAD_MAX_CO + threadIdx.x];
+        row[threadIdx.x * (C8 + 8) + C8] = s;
+      }
+    }
+  }
+}
+
+// ---- MetadataEncoder: tiny; one block, fp32 ------------------------------------------------------
+__global__ void meta_mlp_fwd_kernel(const float* __restrict__ md, const float* __restrict__ w0, const float* __restrict__ b0,
+                                    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ hidden,
+                                    float* __restrict__ emb, int N, int F, int Hd, int D) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * Hd; i += gridDim.x * blockDim.x) {
+    const int n = i / Hd, j = i % Hd;
+    float s = b0[j];
+    for (int f = 0; f < F; ++f) s = fmaf(md[n * F + f], w0[j * F + f], s);
+    hidden[i] = fmaxf(s, 0.f);
+  }
+}
+__global__ void meta_mlp_fwd2_kernel(const float* __restrict__ hidden, const float* __restrict__ w2, const float* __restrict__ b2,
+                                     float* __restrict__ emb, int N, int Hd, int D) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * D; i += gridDim.x * blockDim.x) {
+    const int n = i / D, d = i % D;
+    float s = b2[d];
+    for (int j = 0; j < Hd; ++j) s = fmaf(hidden[n * Hd + j], w2[d * Hd + j], s);
+    emb[i] = s;
+  }
+}
+// one block; N is a batch (<= a few hundred), Hd = 32, D <= 256: everything fits one workgroup's loops
+__global__ void meta_mlp_bwd_kernel(const float* __restrict__ md, const float* __restrict__ w0, const float* __restrict__ w2,
+                                    const float* __restrict__ hidden, const float* __restrict__ demb, float* __restrict__ dw0,
+                                    float* __restrict__ db0, float* __restrict__ dw2, float* __restrict__ db2,
+                                    float* __restrict__ dhid_ws, int N, int F, int Hd, int D) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  for (int i = t; i < D * Hd; i += nt) {       // dW2[d][j] = sum_n demb[n][d] * hidden[n][j]
+    const int d = i / Hd, j = i % Hd;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(demb[n * D + d], hidden[n * Hd + j], s);
+    dw2[i] = s;
+  }
+  for (int d = t; d < D; d += nt) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += demb[n * D + d];
+    db2[d] = s;
+  }
+  for (int i = t; i < N * Hd; i += nt) {       // dhidden (through ReLU)
+    const int n = i / Hd, j = i % Hd;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s = fmaf(demb[n * D + d], w2[d * Hd + j], s);
+    dhid_ws[i] = hidden[i] > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < Hd * F; i += nt) {
+    const int j = i / F, f = i % F;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(dhid_ws[n * Hd + j], md[n * F + f], s);
+    dw0[i] = s;
+  }
+  for (int j = t; j < Hd; j += nt) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dhid_ws[n * Hd + j];
+    db0[j] = s;
+  }
+}
+
+// ---- MSE: per-block fp64 partial of (out-tgt)^2 and dout = 2*(out-tgt)/n -----------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                  double* __restrict__ partial, float* __restrict__ dout, int64_t n, float k) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(out + i), b = *reinterpret_cast<const f32x4*>(tgt + i);
+      f32x4 d = a - b;
+      s += (double)(d[0] * d[0]) + (double)(d[1] * d[1]) + (double)(d[2] * d[2]) + (double)(d[3] * d[3]);
+      if (dout) *reinterpret_cast<f32x4*>(dout + i) = d * k;
+    } else {
+      for (int64_t j = i; j < n; ++j) {
+        const float d = out[j] - tgt[j];
+        s += (double)(d * d);
+        if (dout) dout[j] = d * k;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void mse_final_kernel(const double* __restrict__ partial, int nblocks, double inv_n, float* __restrict__ loss) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += partial[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+
+}  // namespace mau
+
+using namespace mau;
+
+extern "C" {
+
+int mau_head_fwd(const void* a, int lda, const float* w, const float* b, float* out, int tanh0, int dtype, int N, int HW,
+                 int C, int Co, mau_stream_t stream) {
+  MAU_REQUIRE(a && w && b && out && N > 0 && HW > 0 && C > 0, "head_fwd: bad arguments");
+  MAU_REQUIRE(Co >= 1 && Co <= HEAD_MAX_CO, "head_fwd: out_channels must be in [1,%d]", HEAD_MAX_CO);
+  MAU_REQUIRE(lda % 8 == 0 && lda >= round_up(C, 8), "head_fwd: bad ld");
+  const int64_t npix = (int64_t)N * HW;
+  const int grid = stream_grid(npix * 8, 256);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, w, b, out, tanh0, HW, C, Co, npix));
+  return check_launch("head_fwd_kernel");
+}
+
+int mau_head_bwd_rows(int N, int HW) { return ceil_div((int64_t)N * HW, HEAD_PIX_PER_BLOCK); }
+int mau_head_bwd_rowlen(int C, int Co) { return Co * (round_up(C, 8) + 8); }
+
+int mau_head_bwd(const void* a, int lda, const float* w, const float* out, const float* dout, void* da, int ldda,
+                 float* slab, int tanh0, int dtype, int N, int HW, int C, int Co, mau_stream_t stream) {
+  MAU_REQUIRE(a && w && out && dout && da && slab && N > 0 && HW > 0 && C > 0, "head_bwd: bad arguments");
+  MAU_REQUIRE(Co >= 1 && Co <= HEAD_MAX_CO, "head_bwd: out_channels must be in [1,%d]", HEAD_MAX_CO);
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(lda % 8 == 0 && ldda % 8 == 0 && lda >= C8 && ldda >= C8, "head_bwd: bad ld");
+  const int64_t npix = (int64_t)N * HW;
+  const size_t lds = (size_t)32 * HEAD_MAX_CO * 65 * sizeof(float);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(mau_head_bwd_rows(N, HW)), dim3(256), lds, (hipStream_t)stream, (const T*)a, lda, w, out, dout, (T*)da, ldda, slab, tanh0, HW, C, C8, Co, npix));
+  return check_launch("head_bwd_kernel");
+}
+
+int mau_meta_mlp_fwd(const float* md, const float* w0, const float* b0, const float* w2, const float* b2, float* hidden,
+                     float* emb, int N, int F, int Hd, int D, mau_stream_t stream) {
+  MAU_REQUIRE(md && w0 && b0 && w2 && b2 && hidden && emb && N > 0 && F > 0 && Hd > 0 && D > 0, "meta_mlp_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(meta_mlp_fwd_kernel, dim3(ceil_div(N * Hd, 256)), dim3(256), 0, st, md, w0, b0, w2, b2, hidden, emb, N, F, Hd, D);
+  hipLaunchKernelGGL(meta_mlp_fwd2_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, st, hidden, w2, b2, emb, N, Hd, D);
+  return check_launch("meta_mlp_fwd_kernel");
+}
+
+int mau_meta_mlp_bwd(const float* md, const float* w0, const float* w2, const float* hidden, const float* demb, float* dw0,
+                     float* db0, float* dw2, float* db2, float* dhidden_ws, int N, int F, int Hd, int D, mau_stream_t stream) {
+  MAU_REQUIRE(md && w0 && w2 && hidden && demb && dw0 && db0 && dw2 && db2 && dhidden_ws, "meta_mlp_bwd: null pointer");
+  hipLaunchKernelGGL(meta_mlp_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, md, w0, w2, hidden, demb, dw0, db0, dw2, db2, dhidden_ws, N, F, Hd, D);
+  return check_launch("meta_mlp_bwd_kernel");
+}
+
+int mau_mse_blocks(int64_t n) { return stream_grid((n + 3) / 4, 256); }
+
+int mau_mse_fwd_bwd(const float* out, const float* tgt, double* partial, float* loss, float* dout, int64_t n,
+                    mau_stream_t stream) {
+  MAU_REQUIRE(out && tgt && partial && loss && n > 0, "mse_fwd_bwd: bad arguments");
+  MAU_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)tgt % 16) == 0 && (!dout || ((uintptr_t)dout % 16) == 0), "mse_fwd_bwd: 16-byte alignment required");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = mau_mse_blocks(n);
+  hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, st, out, tgt, partial, dout, n, 2.0f / (float)n);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks, 1.0 / (double)n, loss);
+  return check_launch("mse_kernel");
+}
+
+}  // extern "C"

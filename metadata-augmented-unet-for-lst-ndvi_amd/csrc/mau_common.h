@@ -1,0 +1,113 @@
+// mau_common.h -- shared device helpers for libmau_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mau_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace mau {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MAU_REQUIRE(cond, ...)                      \
+  do {                                              \
+    if (!(cond)) {                                  \
+      ::mau::set_error(__VA_ARGS__);                \
+      return MAU_ERR_ARG;                           \
+    }                                               \
+  } while (0)
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---- 8-channel vector access on NHWC-ld tensors (16 B for bf16, 32 B for f32) ----
+struct F8 {
+  float v[8];
+};
+
+template <typename T>
+__device__ __forceinline__ F8 load8(const T* p);
+template <>
+__device__ __forceinline__ F8 load8<float>(const float* p) {
+  F8 r;
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[i] = a[i];
+    r.v[4 + i] = b[i];
+  }
+  return r;
+}
+template <>
+__device__ __forceinline__ F8 load8<bf16>(const bf16* p) {
+  F8 r;
+  bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const F8& r);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const F8& r) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = r.v[i];
+    b[i] = r.v[4 + i];
+  }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <>
+__device__ __forceinline__ void store8<bf16>(bf16* p, const F8& r) {
+  bf16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (bf16)r.v[i];
+  *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+__device__ __forceinline__ F8 zero8() {
+  F8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = 0.f;
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f(T x) {
+  return (float)x;
+}
+
+// grid sizing for streaming kernels: cap at 8 blocks per CU and grid-stride the rest
+static inline int stream_grid(int64_t work_items, int block) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace mau
+
+#define MAU_DISPATCH_DTYPE(dtype, ...)              \
+  do {                                              \
+    if ((dtype) == MAU_F32) {                       \
+      using T = float;                              \
+      __VA_ARGS__;                                  \
+    } else if ((dtype) == MAU_BF16) {               \
+      using T = bf16;                               \
+      __VA_ARGS__;                                  \
+    } else {                                        \
+      ::mau::set_error("bad dtype %d", (int)dtype); \
+      return MAU_ERR_ARG;                           \
+    }                                               \
+  } while (0)

@@ -1,0 +1,348 @@
+// spatial.hip -- layout change at the module boundary, MaxPool2d(2,2), bilinear resize
+// (align_corners=True) fused with the channel concat, and the adjoint of the embedding broadcast.
+// All HBM-streaming, one 8-channel vector (16 B bf16 / 32 B f32) per lane.
+// Reference: src/model.py:57,218 (pool), :219,243-246,111-121 (upsample / _upsample_match),
+// :279-282,136-177 (torch.cat on channels), :248-259,98-108 (embedding broadcast).
+#include "mau_common.h"
+
+namespace mau {
+
+// ---- NCHW fp32 <-> NHWC-ld T -------------------------------------------------------------
+// tile of 64 pixels x 8 channels through LDS so that both sides are coalesced
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int C,
+                                                           int64_t HW, int ld) {
+  // grid: (pixel blocks of 256, channel groups of 8, N)
+  __shared__ float tile[8][256 + 1];
+  const int n = blockIdx.z, c0 = blockIdx.y * 8;
+  const int64_t p0 = (int64_t)blockIdx.x * 256;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    const int64_t p = p0 + threadIdx.x;
+    tile[j][threadIdx.x] = (c < C && p < HW) ? src[((size_t)n * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  const int64_t p = p0 + threadIdx.x;
+  if (p < HW && c0 < ld) {
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = tile[j][threadIdx.x];
+    store8<T>(dst + ((size_t)n * HW + p) * ld + c0, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C,
+                                                           int64_t HW, int ld) {
+  const int n = blockIdx.z, c0 = blockIdx.y * 8;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const F8 v = load8<T>(src + ((size_t)n * HW + p) * ld + c0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (c0 + j < C) dst[((size_t)n * C + c0 + j) * HW + p] = v.v[j];
+}
+
+// ---- MaxPool2d(2,2), floor mode -------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N,
+                                                          int H, int W, int C8) {
+  const int Ho = H / 2, Wo = W / 2, nv = C8 >> 3;
+  const int64_t total = (int64_t)N * Ho * Wo * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % nv) * 8;
+    int64_t t = idx / nv;
+    const int xo = t % Wo;
+    t /= Wo;
+    const int yo = t % Ho;
+    const int n = (int)(t / Ho);
+    const T* b = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * ldx + c;
+    const F8 v00 = load8<T>(b), v01 = load8<T>(b + ldx), v10 = load8<T>(b + (size_t)W * ldx), v11 = load8<T>(b + (size_t)W * ldx + ldx);
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = fmaxf(fmaxf(v00.v[j], v01.v[j]), fmaxf(v10.v[j], v11.v[j]));
+    store8<T>(y + (((size_t)n * Ho + yo) * Wo + xo) * ldy + c, o);
+  }
+}
+
+// one thread per INPUT pixel vector: grad goes to the first maximum of the window (scan order
+// (0,0),(0,1),(1,0),(1,1) with strict '>' as ATen's max_pool2d), uncovered odd rows/cols get 0.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                          T* __restrict__ dx, int lddx, int N, int H, int W, int C8) {
+  const int Ho = H / 2, Wo = W / 2, nv = C8 >> 3;
+  const int64_t total = (int64_t)N * H * W * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % nv) * 8;
+    int64_t t = idx / nv;
+    const int xi = t % W;
+    t /= W;
+    const int yi = t % H;
+    const int n = (int)(t / H);
+    F8 o = zero8();
+    const int yo = yi >> 1, xo = xi >> 1;
+    if (yo < Ho && xo < Wo) {
+      const T* b = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * ldx + c;
+      const F8 v00 = load8<T>(b), v01 = load8<T>(b + ldx), v10 = load8<T>(b + (size_t)W * ldx), v11 = load8<T>(b + (size_t)W * ldx + ldx);
+      const F8 g = load8<T>(dy + (((size_t)n * Ho + yo) * Wo + xo) * lddy + c);
+      const int me = (yi & 1) * 2 + (xi & 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int arg = 0;
+        float m = v00.v[j];
+        if (v01.v[j] > m) { m = v01.v[j]; arg = 1; }
+        if (v10.v[j] > m) { m = v10.v[j]; arg = 2; }
+        if (v11.v[j] > m) { m = v11.v[j]; arg = 3; }
+        o.v[j] = (arg == me) ? g.v[j] : 0.f;
+      }
+    }
+    store8<T>(dx + (((size_t)n * H + yi) * W + xi) * lddx + c, o);
+  }
+}
+
+// ---- bilinear, align_corners=True ------------------------------------------------------------
+// ATen: scale = (in-1)/(out-1) (0 when out == 1); src = scale*dst; i0 = (int)src; i1 = i0 + (i0 < in-1);
+// l1 = src - i0; l0 = 1 - l1.
+__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+__device__ __forceinline__ void ac_src(float scale, int dst, int in, int& i0, int& i1, float& l0, float& l1) {
+  const float s = scale * (float)dst;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ src, int ldsrc, int h, int w, T* __restrict__ dst,
+                                                         int lddst, int choff, int N, int H, int W, int C8) {
+  const int nv = C8 >> 3;
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  const int64_t total = (int64_t)N * H * W * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % nv) * 8;
+    int64_t t = idx / nv;
+    const int xo = t % W;
+    t /= W;
+    const int yo = t % H;
+    const int n = (int)(t / H);
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    ac_src(sy, yo, h, y0, y1, ly0, ly1);
+    ac_src(sx, xo, w, x0, x1, lx0, lx1);
+    const T* b = src + (size_t)n * h * w * ldsrc + c;
+    const F8 v00 = load8<T>(b + ((size_t)y0 * w + x0) * ldsrc), v01 = load8<T>(b + ((size_t)y0 * w + x1) * ldsrc);
+    const F8 v10 = load8<T>(b + ((size_t)y1 * w + x0) * ldsrc), v11 = load8<T>(b + ((size_t)y1 * w + x1) * ldsrc);
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o.v[j] = ly0 * (lx0 * v00.v[j] + lx1 * v01.v[j]) + ly1 * (lx0 * v10.v[j] + lx1 * v11.v[j]);
+    store8<T>(dst + (((size_t)n * H + yo) * W + xo) * lddst + choff + c, o);
+  }
+}
+
+// adjoint in gather form: every source pixel sums the destination pixels that read it, with the
+// same (i0, i1, l0, l1) arithmetic as the forward pass.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ ddst, int ldddst, int choff, int H, int W,
+                                                         T* __restrict__ dsrc, int lddsrc, int N, int h, int w, int C8) {
+  const int nv = C8 >> 3;
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  const int64_t total = (int64_t)N * h * w * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % nv) * 8;
+    int64_t t = idx / nv;
+    const int xi = t % w;
+    t /= w;
+    const int yi = t % h;
+    const int n = (int)(t / h);
+    // destination rows/cols whose source interval can touch (yi, xi): |s*j - i| < 1 (loose bounds, exact test inside)
+    int ja = 0, jb = H - 1, ka = 0, kb = W - 1;
+    if (sy > 0.f) {
+      ja = (int)floorf(((float)yi - 1.f) / sy) - 1;
+      jb = (int)ceilf(((float)yi + 1.f) / sy) + 1;
+      if (ja < 0) ja = 0;
+      if (jb > H - 1) jb = H - 1;
+    }
+    if (sx > 0.f) {
+      ka = (int)floorf(((float)xi - 1.f) / sx) - 1;
+      kb = (int)ceilf(((float)xi + 1.f) / sx) + 1;
+      if (ka < 0) ka = 0;
+      if (kb > W - 1) kb = W - 1;
+    }
+    F8 acc = zero8();
+    for (int j = ja; j <= jb; ++j) {
+      int y0, y1;
+      float ly0, ly1;
+      ac_src(sy, j, h, y0, y1, ly0, ly1);
+      float wy = 0.f;
+      if (y0 == yi) wy += ly0;
+      if (y1 == yi) wy += ly1;
+      if (wy == 0.f && y0 != yi && y1 != yi) continue;
+      for (int k = ka; k <= kb; ++k) {
+        int x0, x1;
+        float lx0, lx1;
+        ac_src(sx, k, w, x0, x1, lx0, lx1);
+        float wx = 0.f;
+        if (x0 == xi) wx += lx0;
+        if (x1 == xi) wx += lx1;
+        if (x0 != xi && x1 != xi) continue;
+        const F8 g = load8<T>(ddst + (((size_t)n * H + j) * W + k) * ldddst + choff + c);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc.v[q] = fmaf(wgt, g.v[q], acc.v[q]);
+      }
+    }
+    store8<T>(dsrc + (((size_t)n * h + yi) * w + xi) * lddsrc + c, acc);
+  }
+}
+
+// dst[..., choff + c] = src[..., c] for c < C (element granularity: tolerates any C / choff), then
+// zero-fill dst channels [choff + C, zero_to)
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const T* __restrict__ src, int ldsrc, T* __restrict__ dst, int lddst,
+                                                            int choff, int zero_to, int64_t npix, int C) {
+  const int span = (zero_to > choff + C ? zero_to : choff + C) - choff;
+  const int64_t total = npix * span;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx / span;
+    const int c = (int)(idx % span);
+    dst[pix * lddst + choff + c] = c < C ? src[pix * ldsrc + c] : (T)0.f;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_vec_kernel(const T* __restrict__ src, int ldsrc, T* __restrict__ dst,
+                                                                int lddst, int choff, int64_t npix, int C8) {
+  const int nv = C8 >> 3;
+  const int64_t total = npix * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx / nv;
+    const int c = (int)(idx % nv) * 8;
+    store8<T>(dst + pix * lddst + choff + c, load8<T>(src + pix * ldsrc + c));
+  }
+}
+
+// dst[n, p, choff + e] = emb[n][e] for every pixel p (materialised broadcast; only used when the channel
+// counts do not fit the 8-channel granularity of the fused loader), then zero-fill up to zero_to
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_fill_kernel(const float* __restrict__ emb, T* __restrict__ dst, int lddst, int choff,
+                                                         int zero_to, int HW, int E, int64_t npix) {
+  const int span = (zero_to > choff + E ? zero_to : choff + E) - choff;
+  const int64_t total = npix * span;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = idx / span;
+    const int c = (int)(idx % span);
+    dst[pix * lddst + choff + c] = c < E ? (T)emb[(pix / HW) * E + c] : (T)0.f;
+  }
+}
+
+// demb[n][e] = sum over the HW pixels of dx[n, :, choff + e]; block per (n, 64-channel group)
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_bwd_kernel(const T* __restrict__ dx, int lddx, int choff, float* __restrict__ demb,
+                                                        int HW, int E) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.y, e = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < E)
+    for (int p = rl; p < HW; p += 4) s += (float)dx[((size_t)n * HW + p) * lddx + choff + e];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && e < E) demb[(size_t)n * E + e] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+}  // namespace mau
+
+using namespace mau;
+
+extern "C" {
+
+int mau_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H, int W, int ld, mau_stream_t stream) {
+  MAU_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld % 8 == 0 && ld >= C, "nchw_to_nhwc: bad arguments");
+  const int64_t HW = (int64_t)H * W;
+  dim3 grid(ceil_div(HW, 256), ceil_div(round_up(C, 8), 8), N);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst, C, HW, ld));
+  return check_launch("nchw_to_nhwc_kernel");
+}
+
+int mau_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int ld, mau_stream_t stream) {
+  MAU_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld % 8 == 0 && ld >= C, "nhwc_to_nchw: bad arguments");
+  const int64_t HW = (int64_t)H * W;
+  dim3 grid(ceil_div(HW, 256), ceil_div(C, 8), N);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, dst, C, HW, ld));
+  return check_launch("nhwc_to_nchw_kernel");
+}
+
+int mau_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int N, int H, int W, int C, mau_stream_t stream) {
+  MAU_REQUIRE(x && y && N > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2x2_fwd: bad arguments");
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C8 && ldy >= C8, "maxpool2x2_fwd: bad ld");
+  const int grid = stream_grid((int64_t)N * (H / 2) * (W / 2) * (C8 / 8), 256);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, N, H, W, C8));
+  return check_launch("maxpool_fwd_kernel");
+}
+
+int mau_maxpool2x2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int dtype, int N, int H, int W,
+                       int C, mau_stream_t stream) {
+  MAU_REQUIRE(x && dy && dx && N > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2x2_bwd: bad arguments");
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldx >= C8 && lddy >= C8 && lddx >= C8, "maxpool2x2_bwd: bad ld");
+  const int grid = stream_grid((int64_t)N * H * W * (C8 / 8), 256);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C8));
+  return check_launch("maxpool_bwd_kernel");
+}
+
+int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst, int lddst, int choff, int dtype, int N,
+                            int H, int W, int C, mau_stream_t stream) {
+  MAU_REQUIRE(src && dst && N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, "resize_bilinear_fwd: bad arguments");
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(ldsrc % 8 == 0 && lddst % 8 == 0 && choff % 8 == 0 && ldsrc >= C8 && lddst >= choff + C8, "resize_bilinear_fwd: bad ld/choff");
+  const int grid = stream_grid((int64_t)N * H * W * (C8 / 8), 256);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(resize_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, N, H, W, C8));
+  return check_launch("resize_fwd_kernel");
+}
+
+int mau_resize_bilinear_bwd(const void* ddst, int ldddst, int choff, int H, int W, void* dsrc, int lddsrc, int dtype, int N,
+                            int h, int w, int C, mau_stream_t stream) {
+  MAU_REQUIRE(ddst && dsrc && N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, "resize_bilinear_bwd: bad arguments");
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(ldddst % 8 == 0 && lddsrc % 8 == 0 && choff % 8 == 0 && lddsrc >= C8 && ldddst >= choff + C8, "resize_bilinear_bwd: bad ld/choff");
+  const int grid = stream_grid((int64_t)N * h * w * (C8 / 8), 256);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(resize_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)ddst, ldddst, choff, H, W, (T*)dsrc, lddsrc, N, h, w, C8));
+  return check_launch("resize_bwd_kernel");
+}
+
+int mau_copy_channels(const void* src, int ldsrc, void* dst, int lddst, int choff, int zero_to, int dtype, int64_t npix,
+                      int C, mau_stream_t stream) {
+  MAU_REQUIRE(src && dst && npix > 0 && C > 0 && ldsrc >= C && lddst >= choff + C && zero_to <= lddst, "copy_channels: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (C % 8 == 0) && (choff % 8 == 0) && (ldsrc % 8 == 0) && (lddst % 8 == 0) && zero_to <= choff + C;
+  if (vec) {
+    const int grid = stream_grid(npix * (C / 8), 256);
+    MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(copy_channels_vec_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)src, ldsrc, (T*)dst, lddst, choff, npix, C));
+  } else {
+    const int span = (zero_to > choff + C ? zero_to : choff + C) - choff;
+    const int grid = stream_grid(npix * span, 256);
+    MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(copy_channels_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)src, ldsrc, (T*)dst, lddst, choff, zero_to, npix, C));
+  }
+  return check_launch("copy_channels_kernel");
+}
+
+int mau_bcast_fill(const float* emb, void* dst, int lddst, int choff, int zero_to, int dtype, int N, int HW, int E,
+                   mau_stream_t stream) {
+  MAU_REQUIRE(emb && dst && N > 0 && HW > 0 && E > 0 && lddst >= choff + E && zero_to <= lddst, "bcast_fill: bad arguments");
+  const int span = (zero_to > choff + E ? zero_to : choff + E) - choff;
+  const int64_t npix = (int64_t)N * HW;
+  const int grid = stream_grid(npix * span, 256);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bcast_fill_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, emb, (T*)dst, lddst, choff, zero_to, HW, E, npix));
+  return check_launch("bcast_fill_kernel");
+}
+
+int mau_bcast_bwd(const void* dx, int lddx, int choff, float* demb, int dtype, int N, int HW, int E, mau_stream_t stream) {
+  MAU_REQUIRE(dx && demb && N > 0 && HW > 0 && E > 0 && lddx >= choff + E, "bcast_bwd: bad arguments");
+  dim3 grid(ceil_div(E, 64), N);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bcast_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)dx, lddx, choff, demb, HW, E));
+  return check_launch("bcast_bwd_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,537 @@
+"""Autograd functions of the hot path; every forward/backward is a call into libmau_hip.so.
+
+Internal activations are "NHWC-ld" tensors: ``torch`` tensors of shape (N, H, W, ld) with
+``ld = roundup(C, 8)``, dtype ``torch.bfloat16`` (throughput mode) or ``torch.float32``
+(parity mode); channels [C, ld) are always zero.  PyTorch only provides device
+memory, streams and the autograd graph; no arithmetic of the path runs in torch.
+
+Reference: src/model.py (VGGBlock :9-21, pool :218, up/_upsample_match :219,243-246,
+fuse_embeddings :248-259, head :284-292), src/utils/losses.py:27-39.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import MAU_BF16, MAU_F32, call, lib
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return MAU_F32
+    if dt == torch.bfloat16:
+        return MAU_BF16
+    raise TypeError(f"unsupported activation dtype {dt}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensor is on '{t.device}'. This is the MI355X-native HIP path; it has no CPU "
+            "fallback. Move the module and its inputs to a 'cuda' (ROCm) device.")
+
+
+def _ld(t: torch.Tensor) -> int:
+    """Pixel stride (elements) of an NHWC-ld tensor or channel-sliced view of one."""
+    n, h, w, _ = t.shape
+    ld = t.stride(2)
+    if t.stride(3) != 1 or t.stride(1) != w * ld or (n > 1 and t.stride(0) != h * w * ld) or ld % 8:
+        raise RuntimeError(f"not an NHWC-ld tensor: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld
+
+
+def _as_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Return t if it is NHWC-ld addressable (16-byte aligned base), else a contiguous copy."""
+    try:
+        _ld(t)
+        if t.data_ptr() % 16 == 0:
+            return t
+    except RuntimeError:
+        pass
+    return t.contiguous()
+
+
+@dataclass
+class Act:
+    """An internal activation: NHWC-ld tensor + its logical channel count."""
+    t: torch.Tensor
+    C: int
+
+    @property
+    def N(self):
+        return self.t.shape[0]
+
+    @property
+    def H(self):
+        return self.t.shape[1]
+
+    @property
+    def W(self):
+        return self.t.shape[2]
+
+
+# --------------------------------------------------------------------------- #
+# packed-weight cache (weights are repacked only when the parameter changed)
+# --------------------------------------------------------------------------- #
+class PackCache:
+    def __init__(self):
+        self._c = {}
+
+    def get(self, w: torch.Tensor, code: int, which: str) -> torch.Tensor:
+        key = (id(w), code, which)
+        ver = (w._version, w.data_ptr())
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        cout, cin = w.shape[0], w.shape[1]
+        dt = torch.float32 if code == MAU_F32 else torch.bfloat16
+        wd = w.detach()
+        if which == "f":
+            buf = torch.empty(lib.mau_conv3x3_packed_elems(code, cout, cin), dtype=dt, device=w.device)
+            call("mau_conv3x3_pack_weights", wd.data_ptr(), buf.data_ptr(), None, code, cout, cin, _stream())
+        else:
+            nf = lib.mau_conv3x3_packed_elems(code, cout, cin)
+            both = torch.empty(nf + lib.mau_conv3x3_packed_elems(code, cin, cout), dtype=dt, device=w.device)
+            call("mau_conv3x3_pack_weights", wd.data_ptr(), both.data_ptr(), both[nf:].data_ptr(), code, cout, cin, _stream())
+            self._c[(id(w), code, "f")] = (ver, both[:nf])
+            buf = both[nf:]
+        self._c[key] = (ver, buf)
+        return buf
+
+    def clear(self):
+        self._c.clear()
+
+
+PACK_CACHE = PackCache()
+
+
+# --------------------------------------------------------------------------- #
+# layout at the boundary
+# --------------------------------------------------------------------------- #
+class ToNHWC(torch.autograd.Function):
+    """(B,C,H,W) fp32 as delivered by collate_fn (src/dataset.py:99-106) -> NHWC-ld."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, dt: torch.dtype):
+        _require_cuda(x, "UrbanPredictor.forward(maps)")
+        x = x.contiguous().float()
+        N, Cc, H, W = x.shape
+        ld = pad8(Cc)
+        out = torch.empty((N, H, W, ld), dtype=dt, device=x.device)
+        call("mau_nchw_to_nhwc", x.data_ptr(), out.data_ptr(), dtype_code(dt), N, Cc, H, W, ld, _stream())
+        ctx.C = Cc
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _as_nhwc(g)
+        N, H, W, _ = g.shape
+        out = torch.empty((N, ctx.C, H, W), dtype=torch.float32, device=g.device)
+        call("mau_nhwc_to_nchw", g.data_ptr(), out.data_ptr(), dtype_code(g.dtype), N, ctx.C, H, W, _ld(g), _stream())
+        return out, None
+
+
+def to_nchw(a: Act) -> torch.Tensor:
+    """Debug/test helper: NHWC-ld -> (N,C,H,W) fp32 (no autograd)."""
+    t = _as_nhwc(a.t.detach())
+    N, H, W, _ = t.shape
+    out = torch.empty((N, a.C, H, W), dtype=torch.float32, device=t.device)
+    call("mau_nhwc_to_nchw", t.data_ptr(), out.data_ptr(), dtype_code(t.dtype), N, a.C, H, W, _ld(t), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# conv3x3 + BatchNorm2d + ReLU
+# --------------------------------------------------------------------------- #
+@dataclass
+class BNState:
+    """Non-tensor configuration of one conv-bn-relu (module buffers are passed as tensors)."""
+    training: bool
+    C0: int                               # logical channels of the tensor source
+    momentum: float = BN_MOMENTUM
+    eps: float = BN_EPS
+    group: object = None                  # torch.distributed process group for SyncBN (None = local BN)
+    world: int = 1
+
+
+def _all_reduce_(t: torch.Tensor, st: BNState):
+    if st.group is not None and st.world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=st.group)
+
+
+class ConvBNReLU(torch.autograd.Function):
+    """relu(bn(conv3x3(cat([x, broadcast(emb)])))) -- one half of VGGBlock.forward (src/model.py:18-21)."""
+
+    @staticmethod
+    def forward(ctx, x, emb, weight, bias, gamma, beta, rmean, rvar, nbt, st: BNState):
+        _require_cuda(x, "conv3x3")
+        x = _as_nhwc(x)
+        N, H, W, _ = x.shape
+        code = dtype_code(x.dtype)
+        dev = x.device
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        E = 0 if emb is None else emb.shape[1]
+        if st.C0 + E != Cin:
+            raise RuntimeError(f"conv3x3: input has {st.C0}+{E} channels, weight expects {Cin}")
+        if emb is not None:
+            emb = emb.contiguous().float()
+        ldx = _ld(x)
+        ldy = pad8(Cout)
+        stream = _stream()
+        wf = PACK_CACHE.get(weight, code, "f")
+        y = torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        scale, shift = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        mean, invstd = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+        npix = N * H * W
+        if st.training:
+            tiles = lib.mau_conv3x3_num_pixel_tiles(N, H, W)
+            cpad = (Cout + 63) // 64 * 64
+            slab = torch.empty((tiles, 2 * cpad), **f32)
+            call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None, E, wf.data_ptr(),
+                 bias.data_ptr(), y.data_ptr(), ldy, Cout, slab.data_ptr(), code, N, H, W, stream)
+            sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)          # [sum(y) | sum(y^2)]
+            call("mau_reduce_rows_f64", slab.data_ptr(), tiles, Cout, 2 * cpad, sums.data_ptr(), stream)
+            call("mau_reduce_rows_f64", slab.data_ptr() + 4 * cpad, tiles, Cout, 2 * cpad, sums.data_ptr() + 8 * Cout, stream)
+            _all_reduce_(sums, st)
+            count = float(npix * st.world)
+            call("mau_bn_finalize_train", sums.data_ptr(), count, gamma.data_ptr(), beta.data_ptr(),
+                 rmean.data_ptr(), rvar.data_ptr(), nbt.data_ptr() if nbt is not None else None,
+                 st.momentum, st.eps, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                 Cout, stream)
+        else:
+            call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
+                 st.eps, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cout, stream)
+            call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None, E, wf.data_ptr(),
+                 bias.data_ptr(), y.data_ptr(), ldy, Cout, None, code, N, H, W, stream)
+        a = torch.empty_like(y)
+        call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), ldy, code,
+             npix, Cout, stream)
+        ctx.st = st
+        ctx.E = E
+        ctx.save_for_backward(x, emb, weight, y, scale, shift, mean, invstd)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, emb, weight, y, scale, shift, mean, invstd = ctx.saved_tensors
+        st: BNState = ctx.st
+        E = ctx.E
+        da = _as_nhwc(da)
+        N, H, W, ldy = y.shape
+        code = dtype_code(y.dtype)
+        dev = y.device
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        npix = N * H * W
+        stream = _stream()
+        f32 = dict(dtype=torch.float32, device=dev)
+        # --- BN + ReLU backward: two passes over (da, y) ---
+        rows = lib.mau_bn_bwd_rows(npix)
+        slab = torch.empty((rows, 2 * Cout), **f32)
+        call("mau_bn_relu_bwd_reduce", da.data_ptr(), _ld(da), y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(),
+             mean.data_ptr(), invstd.data_ptr(), slab.data_ptr(), Cout, code, npix, Cout, stream)
+        sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
+        call("mau_reduce_rows_f64", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), stream)
+        dgamma = sums[Cout:].float()
+        dbeta = sums[:Cout].float()
+        if st.training:
+            _all_reduce_(sums, st)
+            sums_apply, count = sums, float(npix * st.world)
+        else:
+            sums_apply, count = torch.zeros_like(sums), float(npix)     # eval-mode BN is a fixed affine map
+        dy = torch.empty_like(y)
+        call("mau_bn_relu_bwd_apply", da.data_ptr(), _ld(da), y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(),
+             mean.data_ptr(), invstd.data_ptr(), sums_apply.data_ptr(), count, dy.data_ptr(), ldy, code, npix, Cout, stream)
+        # --- weight gradient ---
+        dw = None
+        if ctx.needs_input_grad[2]:
+            acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(Cout, Cin), **f32)
+            call("mau_conv3x3_wgrad", x.data_ptr(), _ld(x), st.C0, emb.data_ptr() if E else None, E, dy.data_ptr(), ldy,
+                 Cout, acc.data_ptr(), code, N, H, W, stream)
+            dw = torch.empty_like(weight)
+            call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), dw.data_ptr(), Cout, Cin, stream)
+        # --- data gradient (same implicit-GEMM kernel, rotated/transposed weight pack) ---
+        dx = demb = None
+        if ctx.needs_input_grad[0] or (E and ctx.needs_input_grad[1]):
+            wd = PACK_CACHE.get(weight, code, "d")
+            ldd = pad8(Cin)
+            dfull = torch.empty((N, H, W, ldd), dtype=y.dtype, device=dev)
+            call("mau_conv3x3_fwd", dy.data_ptr(), ldy, Cout, None, 0, wd.data_ptr(), None, dfull.data_ptr(), ldd, Cin,
+                 None, code, N, H, W, stream)
+            if E:
+                if ctx.needs_input_grad[1]:
+                    demb = torch.empty((N, E), **f32)
+                    call("mau_bcast_bwd", dfull.data_ptr(), ldd, st.C0, demb.data_ptr(), code, N, H * W, E, stream)
+                if ctx.needs_input_grad[0]:
+                    dx = dfull[..., :pad8(st.C0)]            # C0 % 8 == 0 is enforced by the kernel when E > 0
+            else:
+                dx = dfull
+        # conv bias followed by train-mode BN has an identically zero gradient (the batch mean absorbs it)
+        dbias = torch.zeros(Cout, **f32) if ctx.needs_input_grad[3] else None
+        return dx, demb, dw, dbias, dgamma, dbeta, None, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# MaxPool2d(2,2)
+# --------------------------------------------------------------------------- #
+class MaxPool2x2(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2), src/model.py:218."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        x = _as_nhwc(x)
+        N, H, W, _ = x.shape
+        ldy = pad8(C)
+        y = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=x.device)
+        call("mau_maxpool2x2_fwd", x.data_ptr(), _ld(x), y.data_ptr(), ldy, dtype_code(x.dtype), N, H, W, C, _stream())
+        ctx.save_for_backward(x)
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _as_nhwc(dy)
+        N, H, W, _ = x.shape
+        dx = torch.empty((N, H, W, pad8(ctx.C)), dtype=x.dtype, device=x.device)
+        call("mau_maxpool2x2_bwd", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), pad8(ctx.C),
+             dtype_code(x.dtype), N, H, W, ctx.C, _stream())
+        return dx, None
+
+
+# --------------------------------------------------------------------------- #
+# decoder input: cat([skips..., resize(low)]) on channels
+# --------------------------------------------------------------------------- #
+def _resize_into(src, Cs, h, w, dst, choff, N, H, W, code, stream):
+    if choff % 8 == 0:
+        call("mau_resize_bilinear_fwd", src.data_ptr(), _ld(src), h, w, dst.data_ptr(), _ld(dst), choff, code, N, H, W, Cs, stream)
+    else:   # tiny-channel models only: resize to a scratch tensor, then element-granular copy
+        tmp = torch.empty((N, H, W, pad8(Cs)), dtype=dst.dtype, device=dst.device)
+        call("mau_resize_bilinear_fwd", src.data_ptr(), _ld(src), h, w, tmp.data_ptr(), pad8(Cs), 0, code, N, H, W, Cs, stream)
+        call("mau_copy_channels", tmp.data_ptr(), pad8(Cs), dst.data_ptr(), _ld(dst), choff, 0, code, N * H * W, Cs, stream)
+
+
+class ConcatUp(torch.autograd.Function):
+    """torch.cat([skip_0, ..., skip_{k-1}, up(low)], 1) with up = bilinear(align_corners=True).
+
+    ``two_step=True`` reproduces the U-Net decoder (src/model.py:243-246,279-282): x2 upsample, then a
+    second resize to the skip's size only if the sizes differ.  ``two_step=False`` is U-Net++'s
+    direct resize to the target size (src/model.py:111-121).
+    """
+
+    @staticmethod
+    def forward(ctx, low, C_low, two_step, skip_Cs, *skips):
+        low = _as_nhwc(low)
+        skips = [_as_nhwc(s) for s in skips]
+        N, H, W, _ = skips[0].shape
+        h, w = low.shape[1], low.shape[2]
+        code = dtype_code(low.dtype)
+        stream = _stream()
+        Ctot = sum(skip_Cs) + C_low
+        ld = pad8(Ctot)
+        out = torch.empty((N, H, W, ld), dtype=low.dtype, device=low.device)
+        choff = 0
+        npix = N * H * W
+        for s, cs in zip(skips, skip_Cs):
+            call("mau_copy_channels", s.data_ptr(), _ld(s), out.data_ptr(), ld, choff, 0, code, npix, cs, stream)
+            choff += cs
+        mid = None
+        src, sh, sw = low, h, w
+        if two_step and (2 * h, 2 * w) != (H, W):
+            mid = torch.empty((N, 2 * h, 2 * w, pad8(C_low)), dtype=low.dtype, device=low.device)
+            call("mau_resize_bilinear_fwd", low.data_ptr(), _ld(low), h, w, mid.data_ptr(), pad8(C_low), 0, code, N, 2 * h, 2 * w, C_low, stream)
+            src, sh, sw = mid, 2 * h, 2 * w
+        _resize_into(src, C_low, sh, sw, out, choff, N, H, W, code, stream)
+        if ld > Ctot:   # zero the pad channels
+            out[..., Ctot:].zero_()
+        ctx.meta = (C_low, tuple(skip_Cs), (h, w), (H, W), mid is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        C_low, skip_Cs, (h, w), (H, W), two = ctx.meta
+        g = _as_nhwc(g)
+        N = g.shape[0]
+        code = dtype_code(g.dtype)
+        stream = _stream()
+        ldg = _ld(g)
+        npix = N * H * W
+        grads = []
+        choff = 0
+        for cs in skip_Cs:
+            if cs % 8 == 0 and choff % 8 == 0:
+                grads.append(g[..., choff:choff + cs])                     # zero-copy channel slice
+            else:
+                t = torch.empty((N, H, W, pad8(cs)), dtype=g.dtype, device=g.device)
+                call("mau_copy_channels", g.data_ptr() + choff * g.element_size(), ldg,
+                     t.data_ptr(), pad8(cs), 0, pad8(cs), code, npix, cs, stream)
+                grads.append(t)
+            choff += cs
+        if choff % 8 == 0:
+            gsrc, goff, gld = g, choff, ldg
+        else:
+            gsrc = torch.empty((N, H, W, pad8(C_low)), dtype=g.dtype, device=g.device)
+            call("mau_copy_channels", g.data_ptr() + choff * g.element_size(), ldg, gsrc.data_ptr(), pad8(C_low), 0,
+                 pad8(C_low), code, npix, C_low, stream)
+            goff, gld = 0, pad8(C_low)
+        if two:
+            dmid = torch.empty((N, 2 * h, 2 * w, pad8(C_low)), dtype=g.dtype, device=g.device)
+            call("mau_resize_bilinear_bwd", gsrc.data_ptr(), gld, goff, H, W, dmid.data_ptr(), pad8(C_low), code, N, 2 * h, 2 * w, C_low, stream)
+            gsrc, goff, gld, sH, sW = dmid, 0, pad8(C_low), 2 * h, 2 * w
+        else:
+            sH, sW = H, W
+        dlow = torch.empty((N, h, w, pad8(C_low)), dtype=g.dtype, device=g.device)
+        call("mau_resize_bilinear_bwd", gsrc.data_ptr(), gld, goff, sH, sW, dlow.data_ptr(), pad8(C_low), code, N, h, w, C_low, stream)
+        return (dlow, None, None, None, *grads)
+
+
+class BcastCat(torch.autograd.Function):
+    """Materialised cat([x, emb[:, :, None, None].expand(...)], 1) (src/model.py:248-259).
+
+    Only used when channel counts do not fit the fused loader's 8-channel granularity
+    (tiny test models); production shapes take the fused path inside mau_conv3x3_fwd.
+    """
+
+    @staticmethod
+    def forward(ctx, x, C, emb):
+        x = _as_nhwc(x)
+        emb = emb.contiguous().float()
+        N, H, W, _ = x.shape
+        E = emb.shape[1]
+        ld = pad8(C + E)
+        code = dtype_code(x.dtype)
+        out = torch.empty((N, H, W, ld), dtype=x.dtype, device=x.device)
+        stream = _stream()
+        call("mau_copy_channels", x.data_ptr(), _ld(x), out.data_ptr(), ld, 0, 0, code, N * H * W, C, stream)
+        call("mau_bcast_fill", emb.data_ptr(), out.data_ptr(), ld, C, ld, code, N, H * W, E, stream)
+        ctx.meta = (C, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        C, E = ctx.meta
+        g = _as_nhwc(g)
+        N, H, W, _ = g.shape
+        code = dtype_code(g.dtype)
+        stream = _stream()
+        dx = torch.empty((N, H, W, pad8(C)), dtype=g.dtype, device=g.device)
+        call("mau_copy_channels", g.data_ptr(), _ld(g), dx.data_ptr(), pad8(C), 0, pad8(C), code, N * H * W, C, stream)
+        demb = torch.empty((N, E), dtype=torch.float32, device=g.device)
+        call("mau_bcast_bwd", g.data_ptr(), _ld(g), C, demb.data_ptr(), code, N, H * W, E, stream)
+        return dx, None, demb
+
+
+# --------------------------------------------------------------------------- #
+# head
+# --------------------------------------------------------------------------- #
+class Head(torch.autograd.Function):
+    """final 1x1 conv + tanh on channel 0 when out_channels == 2 (src/model.py:284-292)."""
+
+    @staticmethod
+    def forward(ctx, a, C, weight, bias):
+        a = _as_nhwc(a)
+        N, H, W, _ = a.shape
+        Co = weight.shape[0]
+        tanh0 = 1 if Co == 2 else 0
+        out = torch.empty((N, Co, H, W), dtype=torch.float32, device=a.device)
+        w2 = weight.detach().reshape(Co, C).contiguous().float()
+        call("mau_head_fwd", a.data_ptr(), _ld(a), w2.data_ptr(), bias.detach().data_ptr(), out.data_ptr(), tanh0,
+             dtype_code(a.dtype), N, H * W, C, Co, _stream())
+        ctx.save_for_backward(a, w2, out)
+        ctx.meta = (C, Co, tanh0, tuple(weight.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, w2, out = ctx.saved_tensors
+        C, Co, tanh0, wshape = ctx.meta
+        N, H, W, _ = a.shape
+        dout = dout.contiguous().float()
+        da = torch.empty((N, H, W, pad8(C)), dtype=a.dtype, device=a.device)
+        rows, rowlen = lib.mau_head_bwd_rows(N, H * W), lib.mau_head_bwd_rowlen(C, Co)
+        slab = torch.zeros((rows, rowlen), dtype=torch.float32, device=a.device)
+        stream = _stream()
+        call("mau_head_bwd", a.data_ptr(), _ld(a), w2.data_ptr(), out.data_ptr(), dout.data_ptr(), da.data_ptr(), pad8(C),
+             slab.data_ptr(), tanh0, dtype_code(a.dtype), N, H * W, C, Co, stream)
+        red = torch.empty(rowlen, dtype=torch.float32, device=a.device)
+        call("mau_reduce_rows_f32", slab.data_ptr(), rows, rowlen, rowlen, red.data_ptr(), stream)
+        red = red.view(Co, pad8(C) + 8)
+        dw = red[:, :C].reshape(wshape).contiguous()
+        db = red[:, pad8(C)].contiguous()
+        return da, None, dw, db
+
+
+# --------------------------------------------------------------------------- #
+# MetadataEncoder
+# --------------------------------------------------------------------------- #
+class MetaMLP(torch.autograd.Function):
+    """Linear(F,32) -> ReLU -> Linear(32,D), src/model.py:38-48."""
+
+    @staticmethod
+    def forward(ctx, md, w0, b0, w2, b2):
+        _require_cuda(md, "MetadataEncoder")
+        md = md.contiguous().float()
+        N, F = md.shape
+        Hd, D = w0.shape[0], w2.shape[0]
+        hidden = torch.empty((N, Hd), dtype=torch.float32, device=md.device)
+        emb = torch.empty((N, D), dtype=torch.float32, device=md.device)
+        call("mau_meta_mlp_fwd", md.data_ptr(), w0.detach().data_ptr(), b0.detach().data_ptr(), w2.detach().data_ptr(),
+             b2.detach().data_ptr(), hidden.data_ptr(), emb.data_ptr(), N, F, Hd, D, _stream())
+        ctx.save_for_backward(md, w0, w2, hidden)
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        md, w0, w2, hidden = ctx.saved_tensors
+        demb = demb.contiguous().float()
+        N, F = md.shape
+        Hd, D = w0.shape[0], w2.shape[0]
+        dw0, db0 = torch.empty_like(w0), torch.empty(Hd, dtype=torch.float32, device=md.device)
+        dw2, db2 = torch.empty_like(w2), torch.empty(D, dtype=torch.float32, device=md.device)
+        ws = torch.empty((N, Hd), dtype=torch.float32, device=md.device)
+        call("mau_meta_mlp_bwd", md.data_ptr(), w0.detach().data_ptr(), w2.detach().data_ptr(), hidden.data_ptr(),
+             demb.data_ptr(), dw0.data_ptr(), db0.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), N, F, Hd, D,
+             _stream())
+        return None, dw0, db0, dw2, db2
+
+
+# --------------------------------------------------------------------------- #
+# MSE criterion
+# --------------------------------------------------------------------------- #
+class MSELoss(torch.autograd.Function):
+    """F.mse_loss(outputs, targets) (src/utils/losses.py:33) with its gradient produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, out, tgt):
+        _require_cuda(out, "compute_loss_mse")
+        out = out.contiguous().float()
+        tgt = tgt.contiguous().float()
+        n = out.numel()
+        partial = torch.empty(lib.mau_mse_blocks(n), dtype=torch.float64, device=out.device)
+        loss = torch.empty(1, dtype=torch.float32, device=out.device)
+        dout = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        call("mau_mse_fwd_bwd", out.data_ptr(), tgt.data_ptr(), partial.data_ptr(), loss.data_ptr(),
+             dout.data_ptr() if dout is not None else None, n, _stream())
+        ctx.dout = dout
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ctx.dout
+        ctx.dout = None
+        return d * g, None

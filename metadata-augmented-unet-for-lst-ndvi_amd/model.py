@@ -1,0 +1,307 @@
+"""Drop-in mirror of the reference's ``src/model.py`` module surface, running on libmau_hip.
+
+Same class names, constructor signatures, ``forward(maps, temp_series, metadata)`` order,
+parameter/buffer names (``state_dict`` is key- and shape-identical, so reference ``.pth``
+checkpoints load with ``strict=True``) and error behaviour:
+
+    UrbanPredictor            src/model.py:295-329
+    UrbanPredictor_unet       src/model.py:195-292
+    UrbanPredictor_unetpp     src/model.py:51-193
+    VGGBlock                  src/model.py:9-21
+    MetadataEncoder           src/model.py:38-48
+    TemporalEncoder           src/model.py:23-34   (LSTM stays torch.nn.LSTM)
+
+The ``torch.nn`` layers inside are parameter containers created in the reference's order (so the
+same ``torch.manual_seed`` gives the same initial weights); their ``forward`` is never used for
+the hot path -- all arithmetic runs in the HIP kernels behind ``functional``.
+
+Extras that the reference does not have (all optional, defaults keep reference behaviour):
+  * ``model.set_precision("bf16" | "fp32")`` -- throughput mode vs fp32 parity mode
+    (default from env ``MAU_PRECISION``, else "bf16");
+  * ``model.set_sync_bn(process_group)``     -- BatchNorm statistics all-reduced over RCCL.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from .functional import Act, BNState
+
+_DTYPES = {"bf16": torch.bfloat16, "fp32": torch.float32}
+
+
+def _default_precision() -> str:
+    p = os.environ.get("MAU_PRECISION", "bf16").lower()
+    if p not in _DTYPES:
+        raise ValueError(f"MAU_PRECISION must be one of {list(_DTYPES)}, got {p!r}")
+    return p
+
+
+class _Runtime:
+    """Per-model execution settings shared by all blocks of one network."""
+
+    def __init__(self):
+        self.precision = _default_precision()
+        self.group = None
+        self.world = 1
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return _DTYPES[self.precision]
+
+
+class VGGBlock(nn.Module):
+    """(Conv3x3 -> BN -> ReLU) x 2, src/model.py:9-21."""
+
+    def __init__(self, in_channels, middle_channels, out_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, middle_channels, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(middle_channels)
+        self.conv2 = nn.Conv2d(middle_channels, out_channels, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self._rt: Optional[_Runtime] = None
+
+    def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d) -> Act:
+        rt = self._rt or _Runtime()
+        st = BNState(training=self.training and bn.training, C0=x.C, momentum=bn.momentum, eps=bn.eps,
+                     group=rt.group, world=rt.world)
+        t = F_.ConvBNReLU.apply(x.t, emb, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                bn.running_var, bn.num_batches_tracked, st)
+        return Act(t, conv.out_channels)
+
+    def forward(self, x: Act, emb: Optional[torch.Tensor] = None) -> Act:
+        x = self._half(x, emb, self.conv1, self.bn1)
+        return self._half(x, None, self.conv2, self.bn2)
+
+
+class TemporalEncoder(nn.Module):
+    """LSTM(1->hidden) last hidden state -> Linear, src/model.py:23-34."""
+
+    def __init__(self, seq_len, hidden_dim, out_dim):
+        super().__init__()
+        self.lstm = nn.LSTM(input_size=1, hidden_size=hidden_dim, batch_first=True)
+        self.fc = nn.Linear(hidden_dim, out_dim)
+
+    def forward(self, x):
+        _, (h_n, _) = self.lstm(x.unsqueeze(-1))
+        return self.fc(h_n[-1])
+
+
+class MetadataEncoder(nn.Module):
+    """Linear(F,32) -> ReLU -> Linear(32,out), src/model.py:38-48."""
+
+    def __init__(self, in_features, out_dim):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(in_features, 32), nn.ReLU(), nn.Linear(32, out_dim))
+
+    def forward(self, x):
+        return F_.MetaMLP.apply(x, self.fc[0].weight, self.fc[0].bias, self.fc[2].weight, self.fc[2].bias)
+
+
+class _NetBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._rt = _Runtime()
+
+    def _bind_runtime(self):
+        for m in self.modules():
+            if isinstance(m, VGGBlock):
+                m._rt = self._rt
+
+    # -- extras -------------------------------------------------------------
+    def set_precision(self, precision: str):
+        if precision not in _DTYPES:
+            raise ValueError(f"precision must be one of {list(_DTYPES)}")
+        self._rt.precision = precision
+        return self
+
+    def set_sync_bn(self, group=None, world_size: Optional[int] = None):
+        """All-reduce BatchNorm batch statistics over ``group`` (RCCL); ``None``/world 1 = local BN."""
+        import torch.distributed as dist
+        if group is None and not (dist.is_available() and dist.is_initialized()):
+            self._rt.group, self._rt.world = None, 1
+            return self
+        g = group if group is not None else dist.group.WORLD
+        self._rt.group = g
+        self._rt.world = world_size if world_size is not None else dist.get_world_size(g)
+        return self
+
+    def _pool(self, a: Act) -> Act:
+        return Act(F_.MaxPool2x2.apply(a.t, a.C), a.C)
+
+    def _head(self, a: Act) -> torch.Tensor:
+        return F_.Head.apply(a.t, a.C, self.final.weight, self.final.bias)
+
+
+class UrbanPredictor_unet(_NetBase):
+    """src/model.py:195-292."""
+
+    def __init__(self, spatial_channels, seq_len, temporal_dim, meta_features, meta_dim, lstm_dim, out_channels,
+                 nb_filter=None, temporal_embeddings=True, metadata_embeddings=True):
+        super().__init__()
+        if nb_filter is None:
+            nb_filter = [32, 64, 128, 256, 512]
+        self.temporal_dim = temporal_dim
+        self.meta_dim = meta_dim
+        self.temporal_embeddings = temporal_embeddings
+        self.metadata_embeddings = metadata_embeddings
+        self.temporal_encoder = TemporalEncoder(seq_len, hidden_dim=lstm_dim, out_dim=temporal_dim)
+        self.meta_encoder = MetadataEncoder(meta_features, meta_dim)
+        self.pool = nn.MaxPool2d(2, 2)
+        self.up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        self.conv0_0 = VGGBlock(spatial_channels, nb_filter[0], nb_filter[0])
+        self.conv1_0 = VGGBlock(nb_filter[0], nb_filter[1], nb_filter[1])
+        self.conv2_0 = VGGBlock(nb_filter[1], nb_filter[2], nb_filter[2])
+        self.conv3_0 = VGGBlock(nb_filter[2], nb_filter[3], nb_filter[3])
+        bottleneck_in = nb_filter[3]
+        if self.temporal_embeddings:
+            bottleneck_in += temporal_dim
+        if self.metadata_embeddings:
+            bottleneck_in += meta_dim
+        self.conv4_0 = VGGBlock(bottleneck_in, nb_filter[4], nb_filter[4])
+        self.conv3_1 = VGGBlock(nb_filter[3] + nb_filter[4], nb_filter[3], nb_filter[3])
+        self.conv2_1 = VGGBlock(nb_filter[2] + nb_filter[3], nb_filter[2], nb_filter[2])
+        self.conv1_1 = VGGBlock(nb_filter[1] + nb_filter[2], nb_filter[1], nb_filter[1])
+        self.conv0_1 = VGGBlock(nb_filter[0] + nb_filter[1], nb_filter[0], nb_filter[0])
+        self.final = nn.Conv2d(nb_filter[0], out_channels, kernel_size=1)
+        self._bind_runtime()
+
+    def _up_cat(self, skip: Act, low: Act) -> Act:
+        # cat([skip, _upsample_match(up(low), skip)], 1), src/model.py:243-246,279-282
+        t = F_.ConcatUp.apply(low.t, low.C, True, (skip.C,), skip.t)
+        return Act(t, skip.C + low.C)
+
+    def _fused_block(self, block: VGGBlock, x: Act, embs: List[torch.Tensor]) -> Act:
+        """conv4_0(fuse_embeddings(x, ...)) with the broadcast folded into the conv loader (src/model.py:248-259)."""
+        if not embs:
+            return block(x)
+        emb = embs[0] if len(embs) == 1 else torch.cat(embs, dim=1)     # order [temporal, meta]
+        if x.C % 8 == 0 and emb.shape[1] % 8 == 0:
+            return block(x, emb.float())
+        # channel counts that do not fit the 8-channel vector granularity: materialise the concat
+        return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]))
+
+    def forward(self, maps, temp_series, metadata):
+        temporal_emb = self.temporal_encoder(temp_series) if self.temporal_embeddings else None
+        meta_emb = self.meta_encoder(metadata) if self.metadata_embeddings else None
+        x = Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
+        x0_0 = self.conv0_0(x)
+        x1_0 = self.conv1_0(self._pool(x0_0))
+        x2_0 = self.conv2_0(self._pool(x1_0))
+        x3_0 = self.conv3_0(self._pool(x2_0))
+        x4_0 = self._pool(x3_0)
+        x4_0 = self._fused_block(self.conv4_0, x4_0, [e for e in (temporal_emb, meta_emb) if e is not None])
+        x3_1 = self.conv3_1(self._up_cat(x3_0, x4_0))
+        x2_1 = self.conv2_1(self._up_cat(x2_0, x3_1))
+        x1_1 = self.conv1_1(self._up_cat(x1_0, x2_1))
+        x0_1 = self.conv0_1(self._up_cat(x0_0, x1_1))
+        return self._head(x0_1)
+
+
+class UrbanPredictor_unetpp(_NetBase):
+    """src/model.py:51-193 (nested U-Net; embeddings concatenated into every decoder node)."""
+
+    def __init__(self, spatial_channels, seq_len, temporal_dim, meta_features, meta_dim, lstm_dim, out_channels,
+                 base_filters=32, deep_supervision=False, **kwargs):
+        super().__init__()
+        nb = [base_filters, base_filters * 2, base_filters * 4, base_filters * 8, base_filters * 16]
+        self.deep_supervision = deep_supervision
+        self.pool = nn.MaxPool2d(2, 2)
+        self.embed_dim = temporal_dim + meta_dim
+        e = temporal_dim + meta_dim
+        self.conv0_0 = VGGBlock(spatial_channels, nb[0], nb[0])
+        self.conv1_0 = VGGBlock(nb[0], nb[1], nb[1])
+        self.conv2_0 = VGGBlock(nb[1], nb[2], nb[2])
+        self.conv3_0 = VGGBlock(nb[2], nb[3], nb[3])
+        self.conv4_0 = VGGBlock(nb[3], nb[4], nb[4])
+        self.conv0_1 = VGGBlock(nb[0] + nb[1] + e, nb[0], nb[0])
+        self.conv1_1 = VGGBlock(nb[1] + nb[2] + e, nb[1], nb[1])
+        self.conv2_1 = VGGBlock(nb[2] + nb[3] + e, nb[2], nb[2])
+        self.conv3_1 = VGGBlock(nb[3] + nb[4] + e, nb[3], nb[3])
+        self.conv0_2 = VGGBlock(nb[0] * 2 + nb[1] + e, nb[0], nb[0])
+        self.conv1_2 = VGGBlock(nb[1] * 2 + nb[2] + e, nb[1], nb[1])
+        self.conv2_2 = VGGBlock(nb[2] * 2 + nb[3] + e, nb[2], nb[2])
+        self.conv0_3 = VGGBlock(nb[0] * 3 + nb[1] + e, nb[0], nb[0])
+        self.conv1_3 = VGGBlock(nb[1] * 3 + nb[2] + e, nb[1], nb[1])
+        self.conv0_4 = VGGBlock(nb[0] * 4 + nb[1] + e, nb[0], nb[0])
+        self.temporal_encoder = TemporalEncoder(seq_len, hidden_dim=lstm_dim, out_dim=temporal_dim)
+        self.meta_encoder = MetadataEncoder(meta_features, meta_dim)
+        if self.deep_supervision:
+            self.final1 = nn.Conv2d(nb[0], out_channels, kernel_size=1)
+            self.final2 = nn.Conv2d(nb[0], out_channels, kernel_size=1)
+            self.final3 = nn.Conv2d(nb[0], out_channels, kernel_size=1)
+            self.final4 = nn.Conv2d(nb[0], out_channels, kernel_size=1)
+        else:
+            self.final = nn.Conv2d(nb[0], out_channels, kernel_size=1)
+        self._bind_runtime()
+
+    def _node(self, block: VGGBlock, skips: List[Act], below: Act, emb: torch.Tensor) -> Act:
+        # cat([skips..., _upsample_match(below, (H, W)), emb_map], 1), src/model.py:111-121,136-177
+        t = F_.ConcatUp.apply(below.t, below.C, False, tuple(s.C for s in skips), *[s.t for s in skips])
+        x = Act(t, sum(s.C for s in skips) + below.C)
+        if x.C % 8 == 0 and emb.shape[1] % 8 == 0:
+            return block(x, emb)                      # broadcast embedding folded into the conv loader
+        return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]))
+
+    def forward(self, maps, temp_series, metadata):
+        temporal_emb = self.temporal_encoder(temp_series)
+        meta_emb = self.meta_encoder(metadata)
+        emb = torch.cat([temporal_emb, meta_emb], dim=1).float()           # src/model.py:103
+        x = Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
+        x0_0 = self.conv0_0(x)
+        x1_0 = self.conv1_0(self._pool(x0_0))
+        x0_1 = self._node(self.conv0_1, [x0_0], x1_0, emb)
+        x2_0 = self.conv2_0(self._pool(x1_0))
+        x1_1 = self._node(self.conv1_1, [x1_0], x2_0, emb)
+        x0_2 = self._node(self.conv0_2, [x0_0, x0_1], x1_1, emb)
+        x3_0 = self.conv3_0(self._pool(x2_0))
+        x2_1 = self._node(self.conv2_1, [x2_0], x3_0, emb)
+        x1_2 = self._node(self.conv1_2, [x1_0, x1_1], x2_1, emb)
+        x0_3 = self._node(self.conv0_3, [x0_0, x0_1, x0_2], x1_2, emb)
+        x4_0 = self.conv4_0(self._pool(x3_0))
+        x3_1 = self._node(self.conv3_1, [x3_0], x4_0, emb)
+        x2_2 = self._node(self.conv2_2, [x2_0, x2_1], x3_1, emb)
+        x1_3 = self._node(self.conv1_3, [x1_0, x1_1, x1_2], x2_2, emb)
+        x0_4 = self._node(self.conv0_4, [x0_0, x0_1, x0_2, x0_3], x1_3, emb)
+        if self.deep_supervision:
+            return [F_.Head.apply(a.t, a.C, f.weight, f.bias)
+                    for a, f in ((x0_1, self.final1), (x0_2, self.final2), (x0_3, self.final3), (x0_4, self.final4))]
+        return self._head(x0_4)
+
+
+class UrbanPredictor(nn.Module):
+    """Dispatcher, src/model.py:295-329 (same signature; unknown ``model_type`` raises ValueError)."""
+
+    def __init__(self, model_type, spatial_channels, seq_len, temporal_dim, meta_features, meta_dim, lstm_dim,
+                 out_channels, base_filters=64, deep_supervision=False, **kwargs):
+        super().__init__()
+        if model_type == 'unet++':
+            self.model = UrbanPredictor_unetpp(
+                spatial_channels=spatial_channels, seq_len=seq_len, temporal_dim=temporal_dim,
+                meta_features=meta_features, meta_dim=meta_dim, lstm_dim=lstm_dim, out_channels=out_channels,
+                base_filters=base_filters, deep_supervision=deep_supervision, **kwargs)
+        elif model_type == 'unet':
+            self.model = UrbanPredictor_unet(
+                spatial_channels=spatial_channels, seq_len=seq_len, temporal_dim=temporal_dim,
+                meta_features=meta_features, meta_dim=meta_dim, lstm_dim=lstm_dim, out_channels=out_channels,
+                nb_filter=[base_filters, base_filters * 2, base_filters * 4, base_filters * 8, base_filters * 16],
+                **kwargs)
+        else:
+            raise ValueError(f"Unsupported model_type: {model_type}")
+
+    def forward(self, maps, temp_series, metadata):
+        return self.model(maps, temp_series, metadata)
+
+    # extras forwarded to the network
+    def set_precision(self, precision: str):
+        self.model.set_precision(precision)
+        return self
+
+    def set_sync_bn(self, group=None, world_size=None):
+        self.model.set_sync_bn(group, world_size)
+        return self

@@ -1,0 +1,284 @@
+"""GPU parity tests, operator level: every HIP entry point (through the C ABI) against the golden
+fixtures generated from the reference and against the CPU oracle on seeded inputs.
+
+Tolerances: fp32 parity mode <= 1e-3 relative (north star; measured ~1e-6..1e-5);
+bf16 throughput mode has its own looser, documented bound.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import unet_ref as R
+from tests.helpers import load_npz, rel_err, sub, t
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def mau():
+    import mau_amd
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from mau_amd import _lib
+    _lib.check(_lib.lib.mau_device_check(), "mau_device_check")
+    return mau_amd
+
+
+def dev(x):
+    return x.cuda()
+
+
+def to_act(mau, x_nchw, dt):
+    from mau_amd import functional as F_
+    return F_.Act(F_.ToNHWC.apply(dev(x_nchw), dt), x_nchw.shape[1])
+
+
+def from_act(mau, a):
+    from mau_amd import functional as F_
+    return F_.to_nchw(a).cpu()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_layout_roundtrip(mau, dt):
+    g = torch.Generator().manual_seed(0)
+    for shape in [(2, 6, 9, 11), (1, 23, 16, 16), (3, 64, 8, 5)]:
+        x = torch.randn(shape, generator=g)
+        if dt == torch.bfloat16:
+            x = x.bfloat16().float()
+        a = to_act(mau, x, dt)
+        assert a.t.shape[-1] % 8 == 0
+        assert float(a.t[..., shape[1]:].float().abs().sum()) == 0.0      # pad channels are zero
+        assert torch.equal(from_act(mau, a), x)
+
+
+def _exact_int_case(g, N, Cin, Cout, H, W):
+    x = torch.randint(-3, 4, (N, Cin, H, W), generator=g).float()
+    w = torch.randint(-2, 3, (Cout, Cin, 3, 3), generator=g).float()
+    b = torch.randint(-4, 5, (Cout,), generator=g).float()
+    return x, w, b
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (1, 8, 64, 31, 17)])
+def test_conv3x3_exact_integers(mau, dt, shape):
+    """Small-integer data is exact in bf16 and fp32: the MFMA operand/accumulator lane maps, halo
+    handling and edge masking must reproduce torch's conv2d bit for bit (asymmetric weights)."""
+    from mau_amd import functional as F_
+    from mau_amd._lib import call, lib
+    N, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x, w, b = _exact_int_case(g, N, Cin, Cout, H, W)
+    ref = TF.conv2d(x, w, b, padding=1)
+    code = F_.dtype_code(dt)
+    a = to_act(mau, x, dt)
+    wd = dev(w)
+    wf = F_.PACK_CACHE.get(wd, code, "f")
+    y = torch.empty((N, H, W, F_.pad8(Cout)), dtype=dt, device="cuda")
+    tiles = lib.mau_conv3x3_num_pixel_tiles(N, H, W)
+    cpad = (Cout + 63) // 64 * 64
+    slab = torch.zeros((tiles, 2 * cpad), dtype=torch.float32, device="cuda")
+    call("mau_conv3x3_fwd", a.t.data_ptr(), a.t.shape[-1], Cin, None, 0, wf.data_ptr(), dev(b).data_ptr(), y.data_ptr(),
+         y.shape[-1], Cout, slab.data_ptr(), code, N, H, W, torch.cuda.current_stream().cuda_stream)
+    got = from_act(mau, F_.Act(y, Cout))
+    if dt == torch.float32 or float(ref.abs().max()) < 256:
+        assert torch.equal(got, ref)
+    else:       # outputs beyond bf16's exact integer range are rounded once on store
+        assert torch.equal(got, ref.bfloat16().float())
+    assert float(y[..., Cout:].float().abs().sum()) == 0.0
+    # fused BatchNorm partial statistics (fp32 accumulators, before the output rounding)
+    s = slab.sum(0).cpu()
+    assert torch.equal(s[:Cout], ref.sum(dim=(0, 2, 3)))
+    assert torch.equal(s[cpad:cpad + Cout], (ref * ref).sum(dim=(0, 2, 3)))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33)])
+def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
+    from mau_amd import functional as F_
+    from mau_amd._lib import call, lib
+    N, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randint(-2, 3, (N, Cin, H, W), generator=g).float().requires_grad_(True)
+    w = torch.randint(-2, 3, (Cout, Cin, 3, 3), generator=g).float().requires_grad_(True)
+    dy = torch.randint(-2, 3, (N, Cout, H, W), generator=g).float()
+    TF.conv2d(x, w, None, padding=1).backward(dy)
+    code = F_.dtype_code(dt)
+    st = torch.cuda.current_stream().cuda_stream
+    xa, dya = to_act(mau, x.detach(), dt), to_act(mau, dy, dt)
+    wdv = dev(w.detach())
+    wdp = F_.PACK_CACHE.get(wdv, code, "d")
+    dx = torch.empty((N, H, W, F_.pad8(Cin)), dtype=dt, device="cuda")
+    call("mau_conv3x3_fwd", dya.t.data_ptr(), dya.t.shape[-1], Cout, None, 0, wdp.data_ptr(), None, dx.data_ptr(),
+         dx.shape[-1], Cin, None, code, N, H, W, st)
+    got_dx = from_act(mau, F_.Act(dx, Cin))
+    ref_dx = x.grad if (dt == torch.float32 or float(x.grad.abs().max()) < 256) else x.grad.bfloat16().float()
+    assert torch.equal(got_dx, ref_dx)
+    acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(Cout, Cin), dtype=torch.float32, device="cuda")
+    call("mau_conv3x3_wgrad", xa.t.data_ptr(), xa.t.shape[-1], Cin, None, 0, dya.t.data_ptr(), dya.t.shape[-1], Cout,
+         acc.data_ptr(), code, N, H, W, st)
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device="cuda")
+    call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), dw.data_ptr(), Cout, Cin, st)
+    assert torch.equal(dw.cpu(), w.grad)
+
+
+def _vgg_from_golden(mau, d, prefix="sd0"):
+    sd = sub(d, prefix)
+    cin, cmid, cout = sd["conv1.weight"].shape[1], sd["conv1.weight"].shape[0], sd["conv2.weight"].shape[0]
+    blk = mau.VGGBlock(cin, cmid, cout)
+    blk.load_state_dict(sd, strict=True)
+    return blk.cuda()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_g1_vgg_block(mau, tag, prec):
+    from mau_amd import functional as F_
+    from mau_amd.model import _Runtime
+    d = load_npz(f"g1_vgg_{tag}.npz")
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    tol = FP32_TOL if prec == "fp32" else 6e-2
+    blk = _vgg_from_golden(mau, d)
+    blk._rt = _Runtime()
+    blk._rt.precision = prec
+    blk.train()
+    x = dev(t(d["x"])).requires_grad_(True)
+    a_in = F_.Act(F_.ToNHWC.apply(x, dt), x.shape[1])
+    a = blk(a_in)
+    y = from_act(mau, a)
+    assert rel_err(y, t(d["y_train"])) < tol
+    # backward: feed the golden upstream gradient in NHWC
+    dy = to_act(mau, t(d["dy"]), dt).t
+    a.t.backward(dy)
+    assert rel_err(x.grad.cpu(), t(d["dx"])) < tol
+    for k, gref in sub(d, "grad").items():
+        got = dict(blk.named_parameters())[k].grad.cpu()
+        if k.startswith("conv") and k.endswith("bias"):
+            assert float(got.abs().max()) == 0.0 and float(gref.abs().max()) < 1e-4      # exactly zero vs fp noise
+        else:
+            assert rel_err(got, gref) < tol, k
+    sd1 = sub(d, "sd1")
+    for k in ("bn1.running_mean", "bn1.running_var", "bn2.running_mean", "bn2.running_var"):
+        assert rel_err(blk.state_dict()[k].cpu(), sd1[k]) < tol, k
+    assert int(blk.bn1.num_batches_tracked) == int(sd1["bn1.num_batches_tracked"])
+    # eval mode with the post-step running statistics of the REFERENCE
+    blk.load_state_dict(sd1, strict=True)
+    blk.eval()
+    with torch.no_grad():
+        ye = from_act(mau, blk(to_act(mau, t(d["x"]), dt)))
+    assert rel_err(ye, t(d["y_eval"])) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_g2_pool_and_resize(mau, dt):
+    from mau_amd import functional as F_
+    d = load_npz("g2_spatial.npz")
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    q = (lambda v: v) if dt == torch.float32 else (lambda v: v.bfloat16().float())
+    for tag in ("even", "odd", "rect"):
+        x = q(t(d[f"pool_{tag}/x"]))
+        xr = x.clone().requires_grad_(True)
+        yr = R.maxpool2x2(xr)
+        dyv = q(t(d[f"pool_{tag}/dy"]))
+        yr.backward(dyv)
+        xa = to_act(mau, x, dt)
+        xa.t.requires_grad_(True)
+        y = F_.MaxPool2x2.apply(xa.t, xa.C)
+        assert torch.equal(from_act(mau, F_.Act(y, xa.C)), yr.detach())            # max is exact in either dtype
+        y.backward(to_act(mau, dyv, dt).t)
+        assert torch.equal(from_act(mau, F_.Act(xa.t.grad, xa.C)), xr.grad)
+        if dt == torch.float32:
+            assert torch.equal(yr.detach(), t(d[f"pool_{tag}/y"])) and torch.equal(xr.grad, t(d[f"pool_{tag}/dx"]))
+    for kind, two_step in (("up", True), ("resize", False)):
+        for tag in ("x2", "odd", "rect", "one"):
+            if f"{kind}_{tag}/x" not in d:
+                continue
+            x, yref, dy, dxref = (t(d[f"{kind}_{tag}/{k}"]) for k in ("x", "y", "dy", "dx"))
+            N, C, H, W = yref.shape
+            skip = torch.zeros(N, 8, H, W)
+            la = to_act(mau, x, dt)
+            la.t.requires_grad_(True)
+            sa = to_act(mau, skip, dt)
+            out = F_.ConcatUp.apply(la.t, C, two_step, (8,), sa.t)
+            got = from_act(mau, F_.Act(out, 8 + C))
+            assert float(got[:, :8].abs().max()) == 0.0
+            assert rel_err(got[:, 8:], yref) < tol, (kind, tag)
+            gfull = torch.cat([torch.zeros(N, 8, H, W), dy], 1)
+            out.backward(to_act(mau, gfull, dt).t)
+            assert rel_err(from_act(mau, F_.Act(la.t.grad, C)), dxref) < tol, (kind, tag)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_g3_fused_embedding_broadcast(mau, prec):
+    """conv(cat([spatial, bcast(temporal), bcast(meta)])) with the broadcast folded into the loader."""
+    from mau_amd import functional as F_
+    d = load_npz("g3_bottleneck.npz")
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    tol = FP32_TOL if prec == "fp32" else 5e-2
+    sp = to_act(mau, t(d["spatial"]), dt)
+    sp.t.requires_grad_(True)
+    emb = dev(torch.cat([t(d["t_emb"]), t(d["m_emb"])], 1)).requires_grad_(True)
+    w, b = dev(t(d["weight"])).requires_grad_(True), dev(t(d["bias"])).requires_grad_(True)
+    Cout = w.shape[0]
+    ones, zeros = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    # identity BatchNorm in eval mode (mean 0, var 1-eps) isolates the convolution: a = relu(conv + bias)
+    st = F_.BNState(training=False, C0=sp.C, eps=0.0)
+    a = F_.ConvBNReLU.apply(sp.t, emb, w, b, ones.clone().requires_grad_(True), zeros.clone().requires_grad_(True),
+                            zeros.clone(), ones.clone(), None, st)
+    yref = t(d["y"])
+    assert rel_err(from_act(mau, F_.Act(a, Cout)), torch.relu(yref)) < tol
+    # gradient: upstream dy masked by relu on the reference side
+    dy = t(d["dy"])
+    spr, ter, mer = (t(d[k]).requires_grad_(True) for k in ("spatial", "t_emb", "m_emb"))
+    wr = t(d["weight"]).requires_grad_(True)
+    torch.relu(TF.conv2d(R.fuse_embeddings(spr, ter, mer), wr, t(d["bias"]), padding=1)).backward(dy)
+    a.backward(to_act(mau, dy, dt).t)
+    assert rel_err(from_act(mau, F_.Act(sp.t.grad, sp.C)), spr.grad) < tol
+    assert rel_err(emb.grad.cpu(), torch.cat([ter.grad, mer.grad], 1)) < tol
+    assert rel_err(w.grad.cpu(), wr.grad) < tol
+
+
+def test_g3_meta_mlp(mau):
+    e = load_npz("g3_encoders.npz")
+    sd = sub(e, "sd")
+    enc = mau.MetadataEncoder(4, 8)
+    enc.load_state_dict({k[len("meta_encoder."):]: v for k, v in sd.items() if k.startswith("meta_encoder.")})
+    enc = enc.cuda()
+    md = dev(t(e["md"]))
+    out = enc(md)
+    assert rel_err(out.cpu(), t(e["meta_emb"])) < 1e-5
+    out.backward(dev(t(e["d_meta_emb"])))
+    for k, gref in sub(e, "grad").items():
+        assert rel_err(dict(enc.named_parameters())[k].grad.cpu(), gref) < 1e-5, k
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_g4_head(mau, dt):
+    from mau_amd import functional as F_
+    d = load_npz("g4_head.npz")
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    xa = to_act(mau, t(d["x"]), dt)
+    xa.t.requires_grad_(True)
+    w, b = dev(t(d["weight"])).requires_grad_(True), dev(t(d["bias"])).requires_grad_(True)
+    y = F_.Head.apply(xa.t, xa.C, w, b)
+    assert rel_err(y.cpu(), t(d["y"])) < tol
+    y.backward(dev(t(d["dy"])))
+    assert rel_err(from_act(mau, F_.Act(xa.t.grad, xa.C)), t(d["dx"])) < tol
+    assert rel_err(w.grad.cpu(), t(d["d_weight"])) < tol
+    assert rel_err(b.grad.cpu(), t(d["d_bias"])) < tol
+
+
+def test_mse_loss(mau):
+    g = torch.Generator().manual_seed(3)
+    for n in [(2, 2, 17, 13), (3, 2, 64, 64)]:
+        o = torch.randn(n, generator=g).requires_grad_(True)
+        tg = torch.randn(n, generator=g)
+        ref = TF.mse_loss(o, tg)
+        ref.backward()
+        oc = dev(o.detach()).requires_grad_(True)
+        got = mau.compute_loss_mse(oc, dev(tg))
+        assert set(got) == {"total", "mse"}
+        got["total"].backward()
+        assert abs(float(got["total"]) - float(ref)) < 1e-6 * abs(float(ref))
+        assert rel_err(oc.grad.cpu(), o.grad) < 1e-6
