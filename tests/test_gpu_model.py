@@ -49,8 +49,8 @@ def test_fp32_parity_full_model(mau, name):
     worst = 0.0
     for k, gref in sub(d, "grad").items():
         got = params[k].grad.cpu()
-        if ".conv" in k and k.endswith("bias") and "final" not in k:
-            assert float(got.abs().max()) == 0.0 and float(gref.abs().max()) < 1e-4, k
+        if k.endswith(".conv1.bias") or k.endswith(".conv2.bias"):
+            assert float(got.abs().max()) == 0.0 and float(gref.abs().max()) < 5e-3, k
             continue
         e = rel_err(got, gref)
         worst = max(worst, e)
@@ -71,23 +71,44 @@ def test_fp32_parity_full_model(mau, name):
 
 
 @pytest.mark.parametrize("name", FULL)
+def _autocast_yardstick(d, m):
+    """Error of the REFERENCE algorithm itself under torch's CPU bf16 autocast vs its fp32 result:
+    the inherent bf16 noise of this network/fixture (ReLU-mask flips, tiny-batch BatchNorm)."""
+    kw = m["kw"]
+    flags = {k: kw[k] for k in ("temporal_embeddings", "metadata_embeddings") if k in kw}
+    x, ts, md, tgt = (t(d[k]) for k in ("x", "ts", "md", "tgt"))
+    sd = R.clone_state(sub(d, "sd0"), requires_grad=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        out = R.forward(kw["model_type"], sd, x, ts, md, True, **flags)
+    R.loss_mse(out.float(), tgt)["total"].backward()
+    gref = sub(d, "grad")
+    num = sum(float(((sd[k].grad.double() - g.double()) ** 2).sum()) for k, g in gref.items())
+    den = sum(float((g.double() ** 2).sum()) for g in gref.values())
+    return rel_l2(out.detach().float(), t(d["out_train"])), (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("name", FULL)
 def test_bf16_mode_full_model(mau, name):
-    """bf16 throughput mode: documented looser bound (the reference's own bf16 autocast
-    differs from fp32 by ~9e-2 relative L2 at this depth)."""
+    """bf16 throughput mode.  Bound: no worse than 1.5x the error the reference's own operators show
+    under torch's bf16 autocast on the same fixture (+2e-2), see SURVEY D8."""
     d = load_npz(name)
     net, m = build(mau, d, "bf16")
+    out_yard, grad_yard = _autocast_yardstick(d, m)
     x, ts, md, tgt = (t(d[k]).cuda() for k in ("x", "ts", "md", "tgt"))
     net.train()
     out = net(x, ts, md)
-    assert rel_l2(out.cpu(), t(d["out_train"])) < 0.15
+    e_out = rel_l2(out.detach().cpu(), t(d["out_train"]))
     loss = mau.compute_loss_mse(out, tgt)["total"]
-    assert abs(float(loss) - float(d["loss"][0])) < 0.1 * abs(float(d["loss"][0]))
     loss.backward()
     params = dict(net.named_parameters())
     gref = sub(d, "grad")
     num = sum(float(((params[k].grad.cpu().double() - g.double()) ** 2).sum()) for k, g in gref.items())
     den = sum(float((g.double() ** 2).sum()) for g in gref.values())
-    assert (num / den) ** 0.5 < 0.35
+    e_grad = (num / den) ** 0.5
+    print(f"{name}: bf16 out relL2 {e_out:.4f} (autocast yardstick {out_yard:.4f}); grad relL2 {e_grad:.4f} (yardstick {grad_yard:.4f})")
+    assert e_out <= 1.5 * out_yard + 2e-2
+    assert abs(float(loss) - float(d["loss"][0])) < 0.1 * abs(float(d["loss"][0]))
+    assert e_grad <= 1.5 * grad_yard + 2e-2
 
 
 def test_init_matches_reference_seed(mau):
@@ -127,7 +148,7 @@ def test_full_size_known_answer_fp32(mau):
     gn = sum(float((p.grad.double() ** 2).sum()) for p in params.values() if p.grad is not None) ** 0.5
     assert abs(gn - s["grad_norm"]) < 1e-3 * s["grad_norm"]
     for k, ref_norm in s["per_param_grad_norm"].items():
-        if ".conv" in k and k.endswith("bias") and "final" not in k:
+        if k.endswith(".conv1.bias") or k.endswith(".conv2.bias"):
             continue
         got = float(params[k].grad.double().norm())
         assert abs(got - ref_norm) <= 2e-3 * ref_norm + 1e-9, (k, got, ref_norm)
