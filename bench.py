@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train images/s of the Metadata-Augmented U-Net on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is the inner training step of the reference (src/train.py:243-256) on one batch of
+synthetic input already resident in HBM: forward, MSE criterion, backward, AdamW step, zero_grad.
+Workload (BASELINE.json configs[1] / configs[3]): U-Net, base_filters 64, 6x256x256 tiles + 4-dim
+metadata, B = 32 per GPU, bf16 MFMA arithmetic with fp32 accumulation, fp32 master weights.
+Prints ONE JSON line on rank 0 (contract in the task description) carrying `roofline` (dominant
+kernel: the 3x3 implicit-GEMM convolution, timed live with events on the launch stream) and
+`cpu_baseline` (the CPU oracle = port of the reference's torch operators, timed on the host cores).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_F32_TFLOPS = 157.3        # fp32 MFMA peak (same guide)
+
+
+def conv_flops(N, H, W, Cin, Cout):
+    return 2.0 * 9.0 * Cin * Cout * N * H * W
+
+
+class ConvTimer:
+    """Brackets every launch of the dominant kernel (conv3x3 implicit GEMM: forward and data-gradient
+    launches of mau_conv3x3_fwd) with events recorded on the stream the kernel is launched on
+    (torch's current stream, which is what the C ABI receives)."""
+
+    def __init__(self, F_):
+        self.F_ = F_
+        self.records = []
+        self.enabled = False
+        self._orig = F_.call
+
+    def install(self):
+        orig = self._orig
+
+        def call(name, *args):
+            if self.enabled and name == "mau_conv3x3_fwd":
+                # args: x, ldx, C0, emb, E, wpk, bias, y, ldy, Cout, slab, dtype, N, H, W, stream
+                C0, E, Cout, N, H, W = args[2], args[4], args[9], args[12], args[13], args[14]
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig(name, *args)
+                e1.record()
+                self.records.append((e0, e1, conv_flops(N, H, W, C0 + E, Cout)))
+            else:
+                orig(name, *args)
+
+        self.F_.call = call
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = [a.elapsed_time(b) for a, b, _ in self.records]
+        fl = [f for _, _, f in self.records]
+        return dict(launches=len(ms), total_ms=sum(ms), total_flop=sum(fl))
+
+
+def cpu_baseline(steps=3):
+    """The oracle's train step (same torch CPU operators as the reference, fp32) on a bounded sample:
+    B = 2 of the same workload (BASELINE config 1)."""
+    from oracle import unet_ref as R
+    torch.manual_seed(0)
+    flags = dict(temporal_embeddings=False, metadata_embeddings=True)
+    sd = R.clone_state(R.init_state("unet", 6, 10, 64, 4, 64, 96, 2, **flags), requires_grad=True)
+    params = [sd[k] for k in sd if R.is_param(k)]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-3)
+    x, ts, md, tgt = R.synthetic_batch(2)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        R.train_step("unet", sd, opt, x, ts, md, tgt, **flags)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            times.append(dt)
+    med = statistics.median(times)
+    return {"value": 2.0 / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"B=2 of the same workload (U-Net base 64, 6x256x256, fp32, fwd+MSE+bwd+AdamW), "
+                      f"median of {steps} steps after 1 warm-up, {med:.2f} s/step, host has {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE: 32)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--model-type", default="unet", choices=["unet", "unet++"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true", help="per-GPU BatchNorm statistics (reference semantics per device)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/)")
+    args = ap.parse_args()
+
+    import mau_amd
+    from mau_amd import functional as F_
+    from mau_amd.dist import GradSync, init_process_group_from_env
+    import torch.distributed as dist
+
+    rank, local, world = init_process_group_from_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- model / synthetic data --------------------------------------------------
+    torch.manual_seed(0)                       # identical replicas on every rank
+    flags = {} if args.model_type == "unet++" else dict(temporal_embeddings=False, metadata_embeddings=True)
+    net = mau_amd.UrbanPredictor(args.model_type, 6, 10, 64, 4, 64, 96, 2, base_filters=64, **flags)
+    net = net.to(dev).set_precision(args.precision).train()
+    g = torch.Generator().manual_seed(1234 + rank)
+    B, S = args.batch, args.size
+    x = torch.randn(B, 6, S, S, generator=g).to(dev)
+    ts = torch.randn(B, 10, generator=g).to(dev)
+    md = torch.randn(B, 4, generator=g).to(dev)
+    tgt = torch.randn(B, 2, S, S, generator=g).to(dev)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-3, fused=True)   # conf/config.yaml:41,48,52
+    sync = None
+    if world > 1:
+        if not args.no_sync_bn:
+            net.set_sync_bn(dist.group.WORLD)
+        sync = GradSync(net, dist.group.WORLD)
+    losses = torch.zeros(args.steps + args.warmup, device=dev)
+
+    def step(i):
+        out = net(x, ts, md)
+        loss = mau_amd.compute_loss_mse(out, tgt)["total"]
+        if sync is not None:
+            sync.begin()
+        loss.backward()
+        if sync is not None:
+            sync.finish()
+        opt.step()
+        opt.zero_grad()
+        losses[i] = loss.detach()
+
+    timer = ConvTimer(F_)
+    timer.install()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    # ---- forward latency per tile (eval mode, no_grad), outside the timed region -----------------
+    net.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            net(x, ts, md)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nf = 5
+        for _ in range(nf):
+            net(x, ts, md)
+        torch.cuda.synchronize()
+        fwd_ms_per_tile = (time.perf_counter() - t1) / nf / B * 1e3
+    net.train()
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+        return
+
+    conv = timer.summary()
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    achieved = conv["total_flop"] / (conv["total_ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": args.traffic_bytes,
+                "kernel": "conv3x3_igemm_kernel (forward + data-gradient launches)",
+                "launches": conv["launches"], "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
+                "flop_per_launch_avg": conv["total_flop"] / conv["launches"],
+                "share_of_step_time": round(conv["total_ms"] / (elapsed * 1e3), 4)}
+    result = {
+        "metric": "train images/sec (256x256x6->2 U-Net, B=32/GPU)" if args.model_type == "unet" else "train images/sec (U-Net++)",
+        "value": round(B * world * args.steps / elapsed, 2),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.precision,
+        "data": "synthetic",
+        "config": {"workload": f"metadata-{args.model_type} base_filters=64, {B}x6x{S}x{S} tiles + 4-dim metadata per GPU, "
+                               "fwd+MSE+bwd+AdamW (src/train.py:243-256), BASELINE configs[1]",
+                   "global_batch": B * world, "parallelism": f"dp{world}",
+                   "sync_bn": bool(world > 1 and not args.no_sync_bn)},
+        "fwd_ms_per_tile": round(fwd_ms_per_tile, 4),
+        "final_loss": float(losses[-1]),
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+
+
+if __name__ == "__main__":
+    main()
