@@ -61,8 +61,8 @@ int mau_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H
 int mau_conv3x3_kc(int dtype);
 /* Elements (of `dtype`) of a packed weight buffer with `nout` output and `nin` input channels. */
 size_t mau_conv3x3_packed_elems(int dtype, int nout, int nin);
-/* OIHW fp32 weights (Cout,Cin,3,3) -> forward pack `wf` [Cin/KC][9][Cout64][KC] and (optional,
- * may be NULL) data-gradient pack `wd` [Cout/KC][9][Cin64][KC] (taps rotated by 180 degrees). */
+/* OIHW fp32 weights (Cout,Cin,3,3) -> forward pack `wf` [Cin/KC][9][Cout64][KC] and/or data-gradient
+ * pack `wd` [Cout/KC][9][Cin64][KC] (taps rotated by 180 degrees); either may be NULL, not both. */
 int mau_conv3x3_pack_weights(const float* w_oihw, void* wf, void* wd, int dtype, int Cout, int Cin,
                              mau_stream_t stream);
 /* Number of pixel tiles (= rows of the BatchNorm partial-statistics slab) for an N x H x W image batch. */
@@ -88,10 +88,14 @@ size_t mau_conv3x3_wgrad_acc_elems(int Cout, int Cin);
 int mau_conv3x3_unpack_wgrad(const float* acc, float* dw_oihw, int Cout, int Cin, mau_stream_t stream);
 
 /* ---- BatchNorm2d (+ReLU) (src/model.py:13,15,16) ------------------------ */
-/* slab [rows][M] fp32 -> sums[M] fp64 (column sums, deterministic order). */
-int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, mau_stream_t stream);
-/* slab [rows][M] fp32 -> out[M] fp32 (column sums accumulated in fp64). */
-int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, mau_stream_t stream);
+/* slab [rows][M] fp32 -> sums[M] fp64: column sums in two deterministic levels; `ws` is an fp64
+ * workspace of mau_reduce_rows_ws_elems(rows, M) elements (NULL = single level, slow for many rows). */
+size_t mau_reduce_rows_ws_elems(int rows, int M);
+int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, double* ws,
+                        mau_stream_t stream);
+/* same, result rounded to fp32. */
+int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, double* ws,
+                        mau_stream_t stream);
 /* Train mode: sums = [sum(y) | sum(y^2)] (2*C fp64, already all-reduced over ranks when data
  * parallel), count = number of pixels summed.  Writes scale = gamma*invstd, shift = beta - mean*scale,
  * mean, invstd and updates running_mean / running_var (unbiased) / num_batches_tracked exactly as

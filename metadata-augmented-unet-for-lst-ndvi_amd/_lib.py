@@ -32,8 +32,9 @@ PROTOTYPES = {
     "mau_conv3x3_wgrad": (_i, [_p, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_wgrad_acc_elems": (_sz, [_i, _i]),
     "mau_conv3x3_unpack_wgrad": (_i, [_p, _p, _i, _i, _p]),
-    "mau_reduce_rows_f64": (_i, [_p, _i, _i, _i, _p, _p]),
-    "mau_reduce_rows_f32": (_i, [_p, _i, _i, _i, _p, _p]),
+    "mau_reduce_rows_ws_elems": (_sz, [_i, _i]),
+    "mau_reduce_rows_f64": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "mau_reduce_rows_f32": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "mau_bn_finalize_train": (_i, [_p, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
     "mau_bn_coeffs_eval": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p]),
     "mau_bn_relu_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _i64, _i, _p]),

@@ -9,20 +9,50 @@
 
 namespace mau {
 
-// ---- column sums of a row-major fp32 slab [rows][ldrow] -> out[M], accumulated in fp64 ----
-template <typename OutT>
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ slab, int rows, int M, int ldrow,
-                                                          OutT* __restrict__ out) {
-  // block = 64 columns x 4 row-lanes; each wave reads 64 consecutive columns of one row (256 B)
+// ---- column sums of a row-major slab [rows][ldrow] -> out[M], accumulated in fp64 ----
+// Two levels, both deterministic: level 1 cuts the rows into gridDim.y chunks and writes fp64
+// partials [chunk][M]; level 2 (same kernel, one chunk) adds the partials in fixed order.
+// block = 64 columns x 4 row-lanes: each wave reads 64 consecutive columns of one row.
+template <typename InT, typename OutT>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const InT* __restrict__ slab, int rows, int M, int ldrow,
+                                                          OutT* __restrict__ out, int ldout) {
   __shared__ double part[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
-  double s = 0.0;
-  if (col < M)
-    for (int r = rl; r < rows; r += 4) s += (double)slab[(size_t)r * ldrow + col];
-  part[rl][threadIdx.x & 63] = s;
+  const int per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s0 = 0.0, s1 = 0.0;
+  if (col < M) {
+    int r = r0 + rl;
+    for (; r + 4 < r1; r += 8) {
+      s0 += (double)slab[(size_t)r * ldrow + col];
+      s1 += (double)slab[(size_t)(r + 4) * ldrow + col];
+    }
+    if (r < r1) s0 += (double)slab[(size_t)r * ldrow + col];
+  }
+  part[rl][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
-  if (rl == 0 && col < M) out[col] = (OutT)(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (rl == 0 && col < M)
+    out[(size_t)blockIdx.y * ldout + col] = (OutT)(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+constexpr int REDUCE_MAX_CHUNKS = 128;
+static int reduce_chunks(int rows) {
+  int c = rows / 32;
+  if (c > REDUCE_MAX_CHUNKS) c = REDUCE_MAX_CHUNKS;
+  return c < 1 ? 1 : c;
+}
+
+template <typename OutT>
+static int reduce_rows_launch(const float* slab, int rows, int M, int ldrow, OutT* out, double* ws, hipStream_t st) {
+  const int chunks = reduce_chunks(rows);
+  if (chunks == 1 || ws == nullptr) {
+    hipLaunchKernelGGL((reduce_rows_kernel<float, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, slab, rows, M, ldrow, out, M);
+  } else {
+    hipLaunchKernelGGL((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, ldrow, ws, M);
+    hipLaunchKernelGGL((reduce_rows_kernel<double, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, (const double*)ws, chunks, M, M, out, M);
+  }
+  return check_launch("reduce_rows_kernel");
 }
 
 __global__ void bn_finalize_train_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
@@ -63,25 +93,48 @@ __global__ void bn_coeffs_eval_kernel(const float* __restrict__ gamma, const flo
   if (invstd_o) invstd_o[c] = is;
 }
 
+// Thread mapping of the streaming kernels: a thread owns ONE 8-channel vector (per-channel
+// coefficients live in registers) and walks over pixels; consecutive lanes take consecutive
+// channel vectors of a pixel, then the next pixel: fully coalesced, no per-element div/mod.
+struct PixVec {
+  int nvl, PS, v, ps;
+  __device__ __forceinline__ PixVec(int nv) {
+    nvl = nv < 256 ? nv : 256;
+    PS = 256 / nvl;
+    v = threadIdx.x % nvl;
+    ps = threadIdx.x / nvl;
+  }
+};
+static inline int pixvec_pixels_per_block(int nv) {
+  const int nvl = nv < 256 ? nv : 256;
+  return (256 / nvl) * 8;          // 8 pixels per thread
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, T* __restrict__ a, int lda,
-                                                            int64_t npix, int C, int C8) {
+                                                            int64_t npix, int C, int C8, int pixb) {
   const int nv = C8 >> 3;
-  const int64_t total = npix * nv;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t pix = idx / nv;
-    const int c = (int)(idx % nv) * 8;
-    F8 v = load8<T>(y + pix * ldy + c);
-    F8 o;
+  const PixVec m(nv);
+  if (m.ps >= m.PS) return;
+  const int64_t p0 = (int64_t)blockIdx.x * pixb;
+  const int64_t p1 = p0 + pixb < npix ? p0 + pixb : npix;
+  for (int vv = m.v; vv < nv; vv += m.nvl) {
+    const int c = vv * 8;
+    float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int cc = c + j;
-      float r = 0.f;
-      if (cc < C) r = fmaxf(fmaf(v.v[j], scale[cc], shift[cc]), 0.f);
-      o.v[j] = r;
+      const bool ok = c + j < C;
+      sc[j] = ok ? scale[c + j] : 0.f;
+      sh[j] = ok ? shift[c + j] : 0.f;
     }
-    store8<T>(a + pix * lda + c, o);
+    for (int64_t pix = p0 + m.ps; pix < p1; pix += m.PS) {
+      const F8 v = load8<T>(y + pix * ldy + c);
+      F8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] = fmaxf(fmaf(v.v[j], sc[j], sh[j]), 0.f);
+      store8<T>(a + pix * lda + c, o);
+    }
   }
 }
 
@@ -146,30 +199,39 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const double* __restrict__ sums,
                                                                 double inv_count, T* __restrict__ dy, int lddy, int64_t npix,
-                                                                int C, int C8) {
+                                                                int C, int C8, int pixb) {
   const int nv = C8 >> 3;
-  const int64_t total = npix * nv;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t pix = idx / nv;
-    const int c = (int)(idx % nv) * 8;
-    const F8 g = load8<T>(da + pix * ldda + c);
-    const F8 v = load8<T>(y + pix * ldy + c);
-    F8 o;
+  const PixVec m(nv);
+  if (m.ps >= m.PS) return;
+  const int64_t p0 = (int64_t)blockIdx.x * pixb;
+  const int64_t p1 = p0 + pixb < npix ? p0 + pixb : npix;
+  for (int vv = m.v; vv < nv; vv += m.nvl) {
+    const int c = vv * 8;
+    // dy = sc*(dz - m1 - xhat*m2), xhat = (y - mu)*is   ==>   dy = sc*dz - k0 - k1*y
+    float sc[8], sh[8], k0[8], k1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int cc = c + j;
-      float r = 0.f;
-      if (cc < C) {
-        const float sc = scale[cc];
-        const float act = fmaf(v.v[j], sc, shift[cc]);
-        const float dz = act > 0.f ? g.v[j] : 0.f;
-        const float xhat = (v.v[j] - mean[cc]) * invstd[cc];
-        const float m1 = (float)(sums[cc] * inv_count), m2 = (float)(sums[C + cc] * inv_count);
-        r = sc * (dz - m1 - xhat * m2);
-      }
-      o.v[j] = r;
+      const bool ok = cc < C;
+      sc[j] = ok ? scale[cc] : 0.f;
+      sh[j] = ok ? shift[cc] : 0.f;
+      const float mu = ok ? mean[cc] : 0.f, is = ok ? invstd[cc] : 0.f;
+      const float m1 = ok ? (float)(sums[cc] * inv_count) : 0.f, m2 = ok ? (float)(sums[C + cc] * inv_count) : 0.f;
+      k1[j] = sc[j] * m2 * is;
+      k0[j] = sc[j] * m1 - k1[j] * mu;
     }
-    store8<T>(dy + pix * lddy + c, o);
+    for (int64_t pix = p0 + m.ps; pix < p1; pix += m.PS) {
+      const F8 g = load8<T>(da + pix * ldda + c);
+      const F8 v = load8<T>(y + pix * ldy + c);
+      F8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float act = fmaf(v.v[j], sc[j], sh[j]);
+        const float dz = act > 0.f ? g.v[j] : 0.f;
+        o.v[j] = fmaf(sc[j], dz, -fmaf(k1[j], v.v[j], k0[j]));
+      }
+      store8<T>(dy + pix * lddy + c, o);
+    }
   }
 }
 
@@ -179,16 +241,16 @@ using namespace mau;
 
 extern "C" {
 
-int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, mau_stream_t stream) {
+size_t mau_reduce_rows_ws_elems(int rows, int M) { return (size_t)reduce_chunks(rows) * M; }
+
+int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, double* ws, mau_stream_t stream) {
   MAU_REQUIRE(slab && sums && rows > 0 && M > 0 && ldrow >= M, "reduce_rows: bad arguments");
-  hipLaunchKernelGGL(reduce_rows_kernel<double>, dim3(ceil_div(M, 64)), dim3(256), 0, (hipStream_t)stream, slab, rows, M, ldrow, sums);
-  return check_launch("reduce_rows_kernel<double>");
+  return reduce_rows_launch<double>(slab, rows, M, ldrow, sums, ws, (hipStream_t)stream);
 }
 
-int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, mau_stream_t stream) {
+int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, double* ws, mau_stream_t stream) {
   MAU_REQUIRE(slab && out && rows > 0 && M > 0 && ldrow >= M, "reduce_rows: bad arguments");
-  hipLaunchKernelGGL(reduce_rows_kernel<float>, dim3(ceil_div(M, 64)), dim3(256), 0, (hipStream_t)stream, slab, rows, M, ldrow, out);
-  return check_launch("reduce_rows_kernel<float>");
+  return reduce_rows_launch<float>(slab, rows, M, ldrow, out, ws, (hipStream_t)stream);
 }
 
 int mau_bn_finalize_train(const double* sums, double count, const float* gamma, const float* beta,
@@ -214,9 +276,9 @@ int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* s
   MAU_REQUIRE(y && a && scale && shift && npix > 0 && C > 0, "bn_relu_apply: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && lda % 8 == 0 && ldy >= C8 && lda >= C8, "bn_relu_apply: bad ld");
-  const int grid = stream_grid(npix * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)y, ldy, scale, shift, (T*)a, lda, npix, C, C8));
+  const int pixb = pixvec_pixels_per_block(C8 / 8);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)y, ldy, scale, shift, (T*)a, lda, npix, C, C8, pixb));
   return check_launch("bn_relu_apply_kernel");
 }
 
@@ -240,10 +302,10 @@ int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, cons
   MAU_REQUIRE(da && y && dy && sums && npix > 0 && C > 0 && count > 0, "bn_relu_bwd_apply: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && lddy >= C8, "bn_relu_bwd_apply: bad ld");
-  const int grid = stream_grid(npix * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+  const int pixb = pixvec_pixels_per_block(C8 / 8);
+  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, sums,
-                                               1.0 / count, (T*)dy, lddy, npix, C, C8));
+                                               1.0 / count, (T*)dy, lddy, npix, C, C8, pixb));
   return check_launch("bn_relu_bwd_apply_kernel");
 }
 

@@ -404,7 +404,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   constexpr int KC = Cfg<T>::KC;
   const int CoutPad = (Cout + 63) / 64 * 64, CinPad = (Cin + 63) / 64 * 64;
   const int nChF = (Cin + KC - 1) / KC, nChD = (Cout + KC - 1) / KC;
-  const size_t nF = (size_t)nChF * 9 * CoutPad * KC, nD = (size_t)nChD * 9 * CinPad * KC;
+  const size_t nF = wf ? (size_t)nChF * 9 * CoutPad * KC : 0, nD = (size_t)nChD * 9 * CinPad * KC;
   const size_t total = nF + (wd ? nD : 0);
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     if (idx < nF) {
@@ -502,9 +502,9 @@ size_t mau_conv3x3_packed_elems(int dtype, int nout, int nin) {
 
 int mau_conv3x3_pack_weights(const float* w, void* wf, void* wd, int dtype, int Cout, int Cin,
                              mau_stream_t stream) {
-  MAU_REQUIRE(w && wf && Cout > 0 && Cin > 0, "pack_weights: bad arguments");
+  MAU_REQUIRE(w && (wf || wd) && Cout > 0 && Cin > 0, "pack_weights: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  const size_t total = mau_conv3x3_packed_elems(dtype, Cout, Cin) + (wd ? mau_conv3x3_packed_elems(dtype, Cin, Cout) : 0);
+  const size_t total = (wf ? mau_conv3x3_packed_elems(dtype, Cout, Cin) : 0) + (wd ? mau_conv3x3_packed_elems(dtype, Cin, Cout) : 0);
   const int grid = stream_grid((int64_t)total, 256);
   MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(grid), dim3(256), 0, st, w, (T*)wf, (T*)wd, Cout, Cin));
   return check_launch("pack_weights_kernel");

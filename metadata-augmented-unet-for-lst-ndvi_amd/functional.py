@@ -88,32 +88,36 @@ class Act:
 # packed-weight cache (weights are repacked only when the parameter changed)
 # --------------------------------------------------------------------------- #
 class PackCache:
-    def __init__(self):
-        self._c = {}
+    """Packed copies of a conv weight live ON the weight tensor object (attribute ``_mau_pack``), so a
+    cache entry can never outlive or be confused with another tensor; an entry is valid while the
+    tensor's in-place version counter and storage address are unchanged."""
 
     def get(self, w: torch.Tensor, code: int, which: str) -> torch.Tensor:
-        key = (id(w), code, which)
+        store = getattr(w, "_mau_pack", None)
+        if store is None:
+            store = {}
+            try:
+                w._mau_pack = store
+            except Exception:       # pragma: no cover - tensor subclass refusing attributes: no caching
+                pass
         ver = (w._version, w.data_ptr())
-        hit = self._c.get(key)
+        hit = store.get((code, which))
         if hit is not None and hit[0] == ver:
             return hit[1]
         cout, cin = w.shape[0], w.shape[1]
         dt = torch.float32 if code == MAU_F32 else torch.bfloat16
-        wd = w.detach()
+        wsrc = w.detach()
         if which == "f":
             buf = torch.empty(lib.mau_conv3x3_packed_elems(code, cout, cin), dtype=dt, device=w.device)
-            call("mau_conv3x3_pack_weights", wd.data_ptr(), buf.data_ptr(), None, code, cout, cin, _stream())
+            call("mau_conv3x3_pack_weights", wsrc.data_ptr(), buf.data_ptr(), None, code, cout, cin, _stream())
         else:
-            nf = lib.mau_conv3x3_packed_elems(code, cout, cin)
-            both = torch.empty(nf + lib.mau_conv3x3_packed_elems(code, cin, cout), dtype=dt, device=w.device)
-            call("mau_conv3x3_pack_weights", wd.data_ptr(), both.data_ptr(), both[nf:].data_ptr(), code, cout, cin, _stream())
-            self._c[(id(w), code, "f")] = (ver, both[:nf])
-            buf = both[nf:]
-        self._c[key] = (ver, buf)
+            buf = torch.empty(lib.mau_conv3x3_packed_elems(code, cin, cout), dtype=dt, device=w.device)
+            call("mau_conv3x3_pack_weights", wsrc.data_ptr(), None, buf.data_ptr(), code, cout, cin, _stream())
+        store[(code, which)] = (ver, buf)
         return buf
 
     def clear(self):
-        self._c.clear()
+        pass
 
 
 PACK_CACHE = PackCache()
@@ -206,8 +210,10 @@ class ConvBNReLU(torch.autograd.Function):
             call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None, E, wf.data_ptr(),
                  bias.data_ptr(), y.data_ptr(), ldy, Cout, slab.data_ptr(), code, N, H, W, stream)
             sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)          # [sum(y) | sum(y^2)]
-            call("mau_reduce_rows_f64", slab.data_ptr(), tiles, Cout, 2 * cpad, sums.data_ptr(), stream)
-            call("mau_reduce_rows_f64", slab.data_ptr() + 4 * cpad, tiles, Cout, 2 * cpad, sums.data_ptr() + 8 * Cout, stream)
+            ws = torch.empty(2 * lib.mau_reduce_rows_ws_elems(tiles, Cout), dtype=torch.float64, device=dev)
+            call("mau_reduce_rows_f64", slab.data_ptr(), tiles, Cout, 2 * cpad, sums.data_ptr(), ws.data_ptr(), stream)
+            call("mau_reduce_rows_f64", slab.data_ptr() + 4 * cpad, tiles, Cout, 2 * cpad, sums.data_ptr() + 8 * Cout,
+                 ws.data_ptr() + 4 * ws.numel(), stream)
             _all_reduce_(sums, st)
             count = float(npix * st.world)
             call("mau_bn_finalize_train", sums.data_ptr(), count, gamma.data_ptr(), beta.data_ptr(),
@@ -246,7 +252,8 @@ class ConvBNReLU(torch.autograd.Function):
         call("mau_bn_relu_bwd_reduce", da.data_ptr(), _ld(da), y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(),
              mean.data_ptr(), invstd.data_ptr(), slab.data_ptr(), Cout, code, npix, Cout, stream)
         sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
-        call("mau_reduce_rows_f64", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), stream)
+        ws = torch.empty(lib.mau_reduce_rows_ws_elems(rows, 2 * Cout), dtype=torch.float64, device=dev)
+        call("mau_reduce_rows_f64", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), ws.data_ptr(), stream)
         dgamma = sums[Cout:].float()
         dbeta = sums[:Cout].float()
         if st.training:
@@ -469,7 +476,8 @@ class Head(torch.autograd.Function):
         call("mau_head_bwd", a.data_ptr(), _ld(a), w2.data_ptr(), out.data_ptr(), dout.data_ptr(), da.data_ptr(), pad8(C),
              slab.data_ptr(), tanh0, dtype_code(a.dtype), N, H * W, C, Co, stream)
         red = torch.empty(rowlen, dtype=torch.float32, device=a.device)
-        call("mau_reduce_rows_f32", slab.data_ptr(), rows, rowlen, rowlen, red.data_ptr(), stream)
+        ws = torch.empty(lib.mau_reduce_rows_ws_elems(rows, rowlen), dtype=torch.float64, device=a.device)
+        call("mau_reduce_rows_f32", slab.data_ptr(), rows, rowlen, rowlen, red.data_ptr(), ws.data_ptr(), stream)
         red = red.view(Co, pad8(C) + 8)
         dw = red[:, :C].reshape(wshape).contiguous()
         db = red[:, pad8(C)].contiguous()
