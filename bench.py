@@ -48,8 +48,8 @@ class ConvTimer:
 
         def call(name, *args):
             if self.enabled and name == "mau_conv3x3_fwd":
-                # args: x, ldx, C0, emb, E, wpk, bias, y, ldy, Cout, slab, dtype, N, H, W, stream
-                C0, E, Cout, N, H, W = args[2], args[4], args[9], args[12], args[13], args[14]
+                # args: x, ldx, C0, emb, emb_ws, E, wpk, bias, y, ldy, Cout, slab, dtype, N, H, W, stream
+                C0, E, Cout, N, H, W = args[2], args[5], args[10], args[13], args[14], args[15]
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()

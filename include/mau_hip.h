@@ -65,18 +65,21 @@ size_t mau_conv3x3_packed_elems(int dtype, int nout, int nin);
  * pack `wd` [Cout/KC][9][Cin64][KC] (taps rotated by 180 degrees); either may be NULL, not both. */
 int mau_conv3x3_pack_weights(const float* w_oihw, void* wf, void* wd, int dtype, int Cout, int Cin,
                              mau_stream_t stream);
-/* Number of pixel tiles (= rows of the BatchNorm partial-statistics slab) for an N x H x W image batch. */
-int mau_conv3x3_num_pixel_tiles(int N, int H, int W);
+/* Number of pixel tiles (= rows of the BatchNorm partial-statistics slab) for an N x H x W image batch
+ * (8x16-pixel tiles for MAU_F32, 16x16 for MAU_BF16). */
+int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W);
 /* y = conv3x3(cat([x, broadcast(emb)], C)) + bias.
  *   x     NHWC-ld with C0 channels;
  *   emb   optional fp32 (N,E): E extra input channels, constant over (y,x) inside the image and
  *         zero in the padding halo -- fuse_embeddings (src/model.py:248-259) without ever
  *         materialising the tiled map; NULL/E=0 for ordinary convolutions;
+ *   emb_ws  workspace of N*E elements of `dtype` (the embedding in the activation dtype; needed for
+ *         MAU_BF16 when E > 0, ignored otherwise);
  *   wpk   forward pack for Cin = C0+E;  bias fp32 (Cout) or NULL;
  *   slab  optional fp32 [num_pixel_tiles][2][Cout64]: per-tile sum / sum of squares of y over the
  *         tile's valid pixels (first half of train-mode nn.BatchNorm2d, src/model.py:13,15).
  * The same entry point computes the data gradient when given dy and the `wd` pack. */
-int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, int E, const void* wpk,
+int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* wpk,
                     const float* bias, void* y, int ldy, int Cout, float* slab, int dtype, int N, int H,
                     int W, mau_stream_t stream);
 /* dW += x (*) dy:  acc fp32 [9][Cout64][Cin64] (zeroed by this call), reduced over all pixels.

@@ -16,7 +16,7 @@
 // first half of train-mode BatchNorm2d (:13,15: per-channel sum / sum of squares, fused into the
 // epilogue) and fuse_embeddings (:248-259: the broadcast embedding is a second, spatially
 // constant K-source of the loader and is never materialised).
-#include "mau_common.h"
+#include "conv_common.h"
 
 namespace mau {
 
@@ -47,12 +47,6 @@ struct Cfg<bf16> {
   using frag = bf16x8;
 };
 
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
 
 template <typename T>
 __device__ __forceinline__ typename Cfg<T>::frag lds_frag(const T* p) {
@@ -91,22 +85,6 @@ __device__ __forceinline__ uint4 pack_emb<bf16>(const float* e) {
   }
   return __builtin_bit_cast(uint4, t);
 }
-
-struct ConvP {
-  const void* x;
-  int ldx, C0;
-  const float* emb;
-  int E;
-  const void* w;
-  const float* bias;
-  void* y;
-  int ldy, Cout, CoutPad;
-  float* slab;
-  int N, H, W, tilesX, tilesY, nChunks;
-};
-
-// C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
 template <typename T>
 __global__ __launch_bounds__(NT) void conv3x3_igemm_kernel(ConvP p) {
@@ -401,7 +379,7 @@ __global__ __launch_bounds__(NT) void conv3x3_wgrad_kernel(WgradP p) {
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
                                     int Cout, int Cin) {
-  constexpr int KC = Cfg<T>::KC;
+  constexpr int KC = PackKC<T>::value;
   const int CoutPad = (Cout + 63) / 64 * 64, CinPad = (Cin + 63) / 64 * 64;
   const int nChF = (Cin + KC - 1) / KC, nChD = (Cout + KC - 1) / KC;
   const size_t nF = wf ? (size_t)nChF * 9 * CoutPad * KC : 0, nD = (size_t)nChD * 9 * CinPad * KC;
@@ -493,7 +471,7 @@ using namespace mau;
 
 extern "C" {
 
-int mau_conv3x3_kc(int dtype) { return dtype == MAU_F32 ? Cfg<float>::KC : Cfg<bf16>::KC; }
+int mau_conv3x3_kc(int dtype) { return dtype == MAU_F32 ? PackKC<float>::value : PackKC<bf16>::value; }
 
 size_t mau_conv3x3_packed_elems(int dtype, int nout, int nin) {
   const int kc = mau_conv3x3_kc(dtype);
@@ -510,9 +488,16 @@ int mau_conv3x3_pack_weights(const float* w, void* wf, void* wd, int dtype, int 
   return check_launch("pack_weights_kernel");
 }
 
-int mau_conv3x3_num_pixel_tiles(int N, int H, int W) { return N * ceil_div(H, TH) * ceil_div(W, TW); }
+int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W) {
+  return dtype == MAU_BF16 ? conv_bf16_v2_num_pixel_tiles(N, H, W) : N * ceil_div(H, TH) * ceil_div(W, TW);
+}
 
-int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, int E, const void* wpk,
+__global__ void cast_f32_to_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (bf16)src[i];
+}
+
+int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* wpk,
                     const float* bias, void* y, int ldy, int Cout, float* slab, int dtype, int N, int H,
                     int W, mau_stream_t stream) {
   MAU_REQUIRE(x && wpk && y, "conv3x3_fwd: null pointer");
@@ -521,11 +506,22 @@ int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, int E, con
   MAU_REQUIRE(E >= 0 && (E == 0 || (emb && E % 8 == 0 && C0 % 8 == 0)), "conv3x3_fwd: broadcast source needs E%%8==0 and C0%%8==0");
   MAU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wpk % 16) == 0, "conv3x3_fwd: pointers must be 16-byte aligned");
   ConvP p;
-  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.E = E; p.w = wpk; p.bias = bias; p.y = y; p.ldy = ldy;
+  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.emb_lp = nullptr; p.E = E; p.w = wpk; p.bias = bias; p.y = y; p.ldy = ldy;
   p.Cout = Cout; p.CoutPad = round_up(Cout, 64); p.slab = slab; p.N = N; p.H = H; p.W = W;
   p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
   p.nChunks = ceil_div(C0 + E, mau_conv3x3_kc(dtype));
-  MAU_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, (hipStream_t)stream));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MAU_F32) return launch_conv<float>(p, st);
+  if (dtype == MAU_BF16) {
+    if (E > 0) {
+      MAU_REQUIRE(emb_ws != nullptr && ((uintptr_t)emb_ws % 16) == 0, "conv3x3_fwd: bf16 broadcast source needs the (N,E) bf16 workspace emb_ws");
+      hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
+      p.emb_lp = emb_ws;
+    }
+    return launch_conv_bf16_v2(p, st);
+  }
+  set_error("bad dtype %d", dtype);
+  return MAU_ERR_ARG;
 }
 
 size_t mau_conv3x3_wgrad_acc_elems(int Cout, int Cin) { return (size_t)9 * round_up(Cout, 64) * round_up(Cin, 64); }

@@ -1,0 +1,41 @@
+// conv_common.h -- declarations shared by the convolution translation units.
+#pragma once
+#include "mau_common.h"
+
+namespace mau {
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+struct ConvP {
+  const void* x;
+  int ldx, C0;
+  const float* emb;     // fp32 (N,E) broadcast source (float kernels)
+  const void* emb_lp;   // the same in the activation dtype (bf16 kernel), filled by the C entry point
+  int E;
+  const void* w;
+  const float* bias;
+  void* y;
+  int ldy, Cout, CoutPad;
+  float* slab;
+  int N, H, W, tilesX, tilesY, nChunks;
+};
+
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+
+// packed-weight K-chunk per dtype (both 16: one k16 bf16 MFMA step / eight k2 fp32 MFMA steps per tap)
+template <typename T>
+struct PackKC {
+  static constexpr int value = 16;
+};
+
+int launch_conv_bf16_v2(const ConvP& p, hipStream_t st);
+int conv_bf16_v2_num_pixel_tiles(int N, int H, int W);
+
+}  // namespace mau
