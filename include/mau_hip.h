@@ -82,13 +82,17 @@ int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W);
 int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* wpk,
                     const float* bias, void* y, int ldy, int Cout, float* slab, int dtype, int N, int H,
                     int W, mau_stream_t stream);
-/* dW += x (*) dy:  acc fp32 [9][Cout64][Cin64] (zeroed by this call), reduced over all pixels.
- * x is the convolution's input (with the optional broadcast `emb` as in mau_conv3x3_fwd). */
-int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, int E, const void* dy, int lddy,
-                      int Cout, float* acc, int dtype, int N, int H, int W, mau_stream_t stream);
-size_t mau_conv3x3_wgrad_acc_elems(int Cout, int Cin);
-/* acc [9][Cout64][Cin64] -> dw OIHW fp32 (Cout,Cin,3,3). */
-int mau_conv3x3_unpack_wgrad(const float* acc, float* dw_oihw, int Cout, int Cin, mau_stream_t stream);
+/* Weight gradient  dW = x (*) dy  reduced over all pixels, in two steps:
+ *   mau_conv3x3_wgrad        -> acc: fp32 split-K partial slabs [nsplit][9][Cout64][Cin64]
+ *                               (nsplit = mau_conv3x3_wgrad_splits(...); MAU_F32: one slab, zeroed by the call)
+ *   mau_conv3x3_unpack_wgrad -> sums the splits in fixed order and writes OIHW fp32 (Cout,Cin,3,3).
+ * x is the convolution's input (with the optional broadcast `emb` / `emb_ws` as in mau_conv3x3_fwd). */
+int mau_conv3x3_wgrad_splits(int dtype, int N, int H, int W, int Cout, int Cin);
+size_t mau_conv3x3_wgrad_acc_elems(int dtype, int N, int H, int W, int Cout, int Cin);
+int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* dy,
+                      int lddy, int Cout, float* acc, int dtype, int N, int H, int W, mau_stream_t stream);
+int mau_conv3x3_unpack_wgrad(const float* acc, int nsplit, float* dw_oihw, int Cout, int Cin,
+                             mau_stream_t stream);
 
 /* ---- BatchNorm2d (+ReLU) (src/model.py:13,15,16) ------------------------ */
 /* slab [rows][M] fp32 -> sums[M] fp64: column sums in two deterministic levels; `ws` is an fp64

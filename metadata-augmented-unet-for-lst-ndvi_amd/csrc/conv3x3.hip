@@ -252,17 +252,6 @@ __global__ __launch_bounds__(NT) void conv3x3_igemm_kernel(ConvP p) {
 // ------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------
-struct WgradP {
-  const void* x;
-  int ldx, C0;
-  const float* emb;
-  int E;
-  const void* dy;
-  int lddy, Cout, CoutPad, Cin, CinPad;
-  float* acc;
-  int N, H, W, tilesX, tilesY, nTiles;
-};
-
 template <typename T>
 struct WFrag;
 template <>
@@ -411,16 +400,22 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   }
 }
 
-__global__ void unpack_wgrad_kernel(const float* __restrict__ acc, float* __restrict__ dw, int Cout, int Cin,
+// sum of the split-K partial slabs [nsplit][9][CoutPad][CinPad] (fixed order) -> OIHW (Cout,Cin,3,3);
+// threads follow the slab layout (ci fastest) so the nsplit reads per element are coalesced.
+__global__ void unpack_wgrad_kernel(const float* __restrict__ acc, int nsplit, float* __restrict__ dw, int Cout, int Cin,
                                     int CoutPad, int CinPad) {
-  const size_t total = (size_t)Cout * Cin * 9;
+  const size_t total = (size_t)9 * Cout * Cin;
+  const size_t slab = (size_t)9 * CoutPad * CinPad;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     size_t t = idx;
-    const int tap = t % 9;
-    t /= 9;
     const int ci = t % Cin;
-    const int co = (int)(t / Cin);
-    dw[idx] = acc[((size_t)tap * CoutPad + co) * CinPad + ci];
+    t /= Cin;
+    const int co = t % Cout;
+    const int tap = (int)(t / Cout);
+    const float* src = acc + ((size_t)tap * CoutPad + co) * CinPad + ci;
+    float v = 0.f;
+    for (int s = 0; s < nsplit; ++s) v += src[(size_t)s * slab];
+    dw[((size_t)co * Cin + ci) * 9 + tap] = v;
   }
 }
 
@@ -524,31 +519,46 @@ int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_
   return MAU_ERR_ARG;
 }
 
-size_t mau_conv3x3_wgrad_acc_elems(int Cout, int Cin) { return (size_t)9 * round_up(Cout, 64) * round_up(Cin, 64); }
+int mau_conv3x3_wgrad_splits(int dtype, int N, int H, int W, int Cout, int Cin) {
+  return dtype == MAU_BF16 ? wgrad_bf16_v2_splits(N, H, W, Cout, Cin) : 1;
+}
 
-int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, int E, const void* dy, int lddy,
+size_t mau_conv3x3_wgrad_acc_elems(int dtype, int N, int H, int W, int Cout, int Cin) {
+  return (size_t)mau_conv3x3_wgrad_splits(dtype, N, H, W, Cout, Cin) * 9 * round_up(Cout, 64) * round_up(Cin, 64);
+}
+
+int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* dy, int lddy,
                       int Cout, float* acc, int dtype, int N, int H, int W, mau_stream_t stream) {
   MAU_REQUIRE(x && dy && acc, "conv3x3_wgrad: null pointer");
   MAU_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && ldx >= C0 && lddy >= Cout, "conv3x3_wgrad: bad ld");
   MAU_REQUIRE(E >= 0 && (E == 0 || (emb && E % 8 == 0 && C0 % 8 == 0)), "conv3x3_wgrad: broadcast source needs E%%8==0 and C0%%8==0");
   MAU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv3x3_wgrad: pointers must be 16-byte aligned");
   WgradP p;
-  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.E = E; p.dy = dy; p.lddy = lddy; p.Cout = Cout;
+  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.emb_lp = nullptr; p.E = E; p.dy = dy; p.lddy = lddy; p.Cout = Cout;
   p.CoutPad = round_up(Cout, 64); p.Cin = C0 + E; p.CinPad = round_up(C0 + E, 64); p.acc = acc;
   p.N = N; p.H = H; p.W = W; p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
   p.nTiles = N * p.tilesX * p.tilesY;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(acc, 0, mau_conv3x3_wgrad_acc_elems(Cout, C0 + E) * sizeof(float), st) != hipSuccess) {
+  if (dtype == MAU_BF16) {
+    if (E > 0) {
+      MAU_REQUIRE(emb_ws != nullptr && ((uintptr_t)emb_ws % 16) == 0, "conv3x3_wgrad: bf16 broadcast source needs the (N,E) bf16 workspace emb_ws");
+      hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
+      p.emb_lp = emb_ws;
+    }
+    return launch_wgrad_bf16_v2(p, st);        // split-K partial slabs, plain stores (no memset needed)
+  }
+  MAU_REQUIRE(dtype == MAU_F32, "bad dtype %d", dtype);
+  if (hipMemsetAsync(acc, 0, mau_conv3x3_wgrad_acc_elems(dtype, N, H, W, Cout, C0 + E) * sizeof(float), st) != hipSuccess) {
     set_error("conv3x3_wgrad: hipMemsetAsync failed");
     return MAU_ERR_HIP;
   }
-  MAU_DISPATCH_DTYPE(dtype, return launch_wgrad<T>(p, st));
+  return launch_wgrad<float>(p, st);
 }
 
-int mau_conv3x3_unpack_wgrad(const float* acc, float* dw, int Cout, int Cin, mau_stream_t stream) {
-  MAU_REQUIRE(acc && dw && Cout > 0 && Cin > 0, "unpack_wgrad: bad arguments");
+int mau_conv3x3_unpack_wgrad(const float* acc, int nsplit, float* dw, int Cout, int Cin, mau_stream_t stream) {
+  MAU_REQUIRE(acc && dw && Cout > 0 && Cin > 0 && nsplit >= 1, "unpack_wgrad: bad arguments");
   const int grid = stream_grid((int64_t)Cout * Cin * 9, 256);
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, dw, Cout, Cin,
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, nsplit, dw, Cout, Cin,
                      round_up(Cout, 64), round_up(Cin, 64));
   return check_launch("unpack_wgrad_kernel");
 }

@@ -25,8 +25,6 @@
 
 namespace mau {
 
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
-
 namespace v2 {
 constexpr int TS = 16;                 // spatial tile side
 constexpr int HS = TS + 2;             // halo side

@@ -4,6 +4,9 @@
 
 namespace mau {
 
+// 16 zero bytes in global memory: DMA source of padding pixels / channels (one copy per translation unit)
+static __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -29,6 +32,21 @@ struct ConvP {
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
 
+// ------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------
+struct WgradP {
+  const void* x;
+  int ldx, C0;
+  const float* emb;
+  const void* emb_lp;   // embedding in the activation dtype (bf16 kernel)
+  int E;
+  const void* dy;
+  int lddy, Cout, CoutPad, Cin, CinPad;
+  float* acc;
+  int N, H, W, tilesX, tilesY, nTiles;
+};
+
 // packed-weight K-chunk per dtype (both 16: one k16 bf16 MFMA step / eight k2 fp32 MFMA steps per tap)
 template <typename T>
 struct PackKC {
@@ -37,5 +55,7 @@ struct PackKC {
 
 int launch_conv_bf16_v2(const ConvP& p, hipStream_t st);
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W);
+int launch_wgrad_bf16_v2(const WgradP& p, hipStream_t st);      // writes nsplit partial slabs (plain stores)
+int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin);
 
 }  // namespace mau

@@ -270,11 +270,13 @@ class ConvBNReLU(torch.autograd.Function):
         # --- weight gradient ---
         dw = None
         if ctx.needs_input_grad[2]:
-            acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(Cout, Cin), **f32)
-            call("mau_conv3x3_wgrad", x.data_ptr(), _ld(x), st.C0, emb.data_ptr() if E else None, E, dy.data_ptr(), ldy,
-                 Cout, acc.data_ptr(), code, N, H, W, stream)
+            acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), **f32)
+            emb_ws = torch.empty((N, E), dtype=y.dtype, device=dev) if E else None
+            call("mau_conv3x3_wgrad", x.data_ptr(), _ld(x), st.C0, emb.data_ptr() if E else None,
+                 emb_ws.data_ptr() if E else None, E, dy.data_ptr(), ldy, Cout, acc.data_ptr(), code, N, H, W, stream)
             dw = torch.empty_like(weight)
-            call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), dw.data_ptr(), Cout, Cin, stream)
+            call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin),
+                 dw.data_ptr(), Cout, Cin, stream)
         # --- data gradient (same implicit-GEMM kernel, rotated/transposed weight pack) ---
         dx = demb = None
         if ctx.needs_input_grad[0] or (E and ctx.needs_input_grad[1]):

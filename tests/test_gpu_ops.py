@@ -94,7 +94,8 @@ def test_conv3x3_exact_integers(mau, dt, shape):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33)])
+@pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (3, 64, 128, 24, 40),
+                                   (2, 136, 256, 16, 16)])
 def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
     from mau_amd import functional as F_
     from mau_amd._lib import call, lib
@@ -115,11 +116,12 @@ def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
     got_dx = from_act(mau, F_.Act(dx, Cin))
     ref_dx = x.grad if (dt == torch.float32 or float(x.grad.abs().max()) < 256) else x.grad.bfloat16().float()
     assert torch.equal(got_dx, ref_dx)
-    acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(Cout, Cin), dtype=torch.float32, device="cuda")
-    call("mau_conv3x3_wgrad", xa.t.data_ptr(), xa.t.shape[-1], Cin, None, 0, dya.t.data_ptr(), dya.t.shape[-1], Cout,
+    acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), dtype=torch.float32, device="cuda")
+    call("mau_conv3x3_wgrad", xa.t.data_ptr(), xa.t.shape[-1], Cin, None, None, 0, dya.t.data_ptr(), dya.t.shape[-1], Cout,
          acc.data_ptr(), code, N, H, W, st)
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device="cuda")
-    call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), dw.data_ptr(), Cout, Cin, st)
+    call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin), dw.data_ptr(),
+         Cout, Cin, st)
     assert torch.equal(dw.cpu(), w.grad)
 
 
