@@ -400,22 +400,26 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   }
 }
 
-// sum of the split-K partial slabs [nsplit][9][CoutPad][CinPad] (fixed order) -> OIHW (Cout,Cin,3,3);
-// threads follow the slab layout (ci fastest) so the nsplit reads per element are coalesced.
-__global__ void unpack_wgrad_kernel(const float* __restrict__ acc, int nsplit, float* __restrict__ dw, int Cout, int Cin,
-                                    int CoutPad, int CinPad) {
-  const size_t total = (size_t)9 * Cout * Cin;
-  const size_t slab = (size_t)9 * CoutPad * CinPad;
+// sum of the split-K partial slabs [nsplit][9][CoutPad][CinPad] (fixed order) -> OIHW (Cout,Cin,3,3).
+// One thread per (co, ci): the nsplit x 9 reads are coalesced over ci, the 9 results are one
+// contiguous 36-byte run of the output (consecutive threads -> consecutive runs).
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ acc, int nsplit, float* __restrict__ dw,
+                                                           int Cout, int Cin, int CoutPad, int CinPad) {
+  const size_t total = (size_t)Cout * Cin;
+  const size_t plane = (size_t)CoutPad * CinPad, slab = 9 * plane;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    size_t t = idx;
-    const int ci = t % Cin;
-    t /= Cin;
-    const int co = t % Cout;
-    const int tap = (int)(t / Cout);
-    const float* src = acc + ((size_t)tap * CoutPad + co) * CinPad + ci;
-    float v = 0.f;
-    for (int s = 0; s < nsplit; ++s) v += src[(size_t)s * slab];
-    dw[((size_t)co * Cin + ci) * 9 + tap] = v;
+    const int ci = idx % Cin;
+    const int co = (int)(idx / Cin);
+    const float* src = acc + (size_t)co * CinPad + ci;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[t] += src[(size_t)sp * slab + (size_t)t * plane];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw[idx * 9 + t] = v[t];
   }
 }
 
@@ -557,7 +561,7 @@ int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* em
 
 int mau_conv3x3_unpack_wgrad(const float* acc, int nsplit, float* dw, int Cout, int Cin, mau_stream_t stream) {
   MAU_REQUIRE(acc && dw && Cout > 0 && Cin > 0 && nsplit >= 1, "unpack_wgrad: bad arguments");
-  const int grid = stream_grid((int64_t)Cout * Cin * 9, 256);
+  const int grid = stream_grid((int64_t)Cout * Cin, 256);
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, nsplit, dw, Cout, Cin,
                      round_up(Cout, 64), round_up(Cin, 64));
   return check_launch("unpack_wgrad_kernel");

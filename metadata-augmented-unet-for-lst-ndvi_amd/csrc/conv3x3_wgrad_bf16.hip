@@ -200,13 +200,29 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   const int bco = (CoutPad % 128 == 0) ? 128 : 64;
   const int outTiles = (CoutPad / bco) * (CinPad / 64);
   const int nTiles = N * ceil_div(H, wg2::TH) * ceil_div(W, wg2::TW);
-  const int target = bco == 128 ? 256 : 512;        // workgroups resident on the chip (1 | 2 per CU)
-  int s = (target + outTiles - 1) / outTiles;
-  if (s > nTiles) s = nTiles;
+  // one workgroup per CU is resident (LDS / accumulator budget): pick the split count whose total
+  // workgroup count fills whole rounds of 256 CUs, preferring fewer splits (less slab traffic) and
+  // at least 4 pixel tiles per workgroup (pipeline fill).
   const size_t slab_bytes = (size_t)9 * CoutPad * CinPad * sizeof(float);
-  const size_t cap = ((size_t)256 << 20) / slab_bytes;             // keep the partial slabs under 256 MiB
-  if ((size_t)s > cap) s = (int)cap;
-  return s < 1 ? 1 : s;
+  size_t cap = ((size_t)256 << 20) / slab_bytes;                 // keep the partial slabs under 256 MiB
+  if (cap < 1) cap = 1;
+  int smax = nTiles / 4;
+  if (smax < 1) smax = 1;
+  if (smax > 1024) smax = 1024;
+  if ((size_t)smax > cap) smax = (int)cap;
+  int best = 1;
+  double best_score = -1.0;
+  for (int s = 1; s <= smax; ++s) {
+    const long blocks = (long)outTiles * s;
+    const long rounds = (blocks + 255) / 256;
+    const double eff = (double)blocks / (double)(rounds * 256);
+    const double score = eff - 0.0015 * s;
+    if (score > best_score + 1e-9) {
+      best_score = score;
+      best = s;
+    }
+  }
+  return best;
 }
 
 int launch_wgrad_bf16_v2(const WgradP& p, hipStream_t st) {
