@@ -39,6 +39,14 @@ typedef __attribute__((address_space(1))) const void* glb_ptr;
 
 __device__ __forceinline__ int swz_off(int row, int half) { return row * ROWB + 16 * (half ^ ((row >> 3) & 1)); }
 
+// ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (same for
+// lanes 32-63).  The assignment "MFMA row/column index i -> tile row" is ours to choose: perm32 sends
+// the first group to rows 0..15 and the second to rows 16..31, so every group reads 16 CONSECUTIVE
+// 32-byte rows, which the (row>>3)&1 chunk swizzle spreads over the 16 distinct 16-byte bank slots.
+__device__ __forceinline__ int perm32(int i) {
+  return i < 4 ? i : i < 12 ? i + 12 : i < 16 ? i - 8 : i < 20 ? i + 8 : i < 28 ? i - 12 : i;
+}
+
 template <int BN>
 __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt) {
   constexpr int NW = BN / 16;                         // waves per workgroup
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;            // 4 (pixel rows) x BN/64 (channels)
-  const int i32 = lane & 31, h = lane >> 5;
+  const int i32 = perm32(lane & 31), h = lane >> 5;   // tile row (pixel / channel) this lane's operands come from
 
   // ---- XCD-aware block -> (pixel tile, cout tile) map ----
   const int P = blockIdx.x;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int prow = acc_row(r, h);
+        const int prow = perm32(acc_row(r, h));
         const int pw = mt * 32 + prow;                               // pixel inside the wave tile
         const int gy = ty0 + wm * 4 + (pw >> 4), gx = tx0 + (pw & 15);
         const float v = acc[mt][nt][r] + bv;

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun):
+#   scripts/profile.sh <tag>      -> gpurun_out/prof_<tag>/{stats,pmc_*}/...
+# kernel-trace/--stats and every --pmc set run as SEPARATE passes (gpurun refuses --pmc together
+# with sys/hip/hsa tracing, and FETCH_SIZE / WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md).
+set -u
+TAG=${1:-r1}
+OUT=gpurun_out/prof_${TAG}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
+echo "stats pass rc=$?"
+i=0
+for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/pmc_$i" -- $BENCH > "$OUT/pmc_$i.log" 2>&1
+  echo "pmc pass $i ($PMC) rc=$?"
+done
+ls -R "$OUT" | head -40

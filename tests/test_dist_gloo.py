@@ -1,0 +1,114 @@
+"""Data-parallel path on CPU: world_size 2, gloo backend (the same code runs over RCCL on the GPUs).
+
+ * GradSync: bucketed, hook-driven gradient averaging == single-process gradients on the joint batch,
+   including a parameter that never receives a gradient.
+ * SyncBN exchange: the [sum | sum of squares] all-reduce used by functional.ConvBNReLU reproduces the
+   reference's single-device statistics on the joint batch (fixture G8, generated from the reference).
+"""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import unet_ref as R
+from tests.helpers import load_npz, rel_err, sub, t
+
+WORLD = 2
+
+
+class TinyNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.unused = torch.nn.Linear(3, 3)             # never used in forward -> grad stays None
+        self.a = torch.nn.Linear(5, 16)
+        self.b = torch.nn.Linear(16, 16)
+        self.c = torch.nn.Linear(16, 2)
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+
+
+def _worker_gradsync(rank, init_file, out_dir):
+    import mau_amd
+    from mau_amd.dist import GradSync
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=WORLD)
+    torch.manual_seed(0)
+    net = TinyNet()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 5, generator=g)
+    y = torch.randn(8, 2, generator=g)
+    xs, ys = x.chunk(WORLD)[rank], y.chunk(WORLD)[rank]
+    sync = GradSync(net, bucket_bytes=256)              # tiny buckets -> several collectives, exercised in order
+    assert len(sync.buckets) > 2
+    for step in range(2):                               # second step checks re-arming after zero_grad
+        sync.begin()
+        torch.nn.functional.mse_loss(net(xs), ys).backward()
+        sync.finish()
+        grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()}
+        net.zero_grad(set_to_none=True)
+    torch.save(grads, os.path.join(out_dir, f"grads_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradsync_world2_matches_single_process(tmp_path):
+    init = tempfile.mktemp(dir=tmp_path)
+    mp.spawn(_worker_gradsync, args=(init, str(tmp_path)), nprocs=WORLD, join=True)
+    torch.manual_seed(0)
+    net = TinyNet()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 5, generator=g)
+    y = torch.randn(8, 2, generator=g)
+    torch.nn.functional.mse_loss(net(x), y).backward()      # mean over the joint batch == mean of per-rank means
+    g0 = torch.load(os.path.join(tmp_path, "grads_0.pt"))
+    g1 = torch.load(os.path.join(tmp_path, "grads_1.pt"))
+    for k, p in net.named_parameters():
+        if k.startswith("unused"):
+            assert g0[k] is None and g1[k] is None
+            continue
+        assert torch.equal(g0[k], g1[k]), k                  # identical on every rank
+        assert rel_err(g0[k], p.grad) < 1e-6, k
+
+
+def _worker_syncbn(rank, init_file, out_dir):
+    import mau_amd
+    from mau_amd.functional import BNState, _all_reduce_
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=WORLD)
+    d = load_npz("g8_syncbn.npz")
+    sd0 = sub(d, "sd0")
+    x = t(d["x"]).chunk(WORLD)[rank]
+    y1 = torch.nn.functional.conv2d(x, sd0["conv1.weight"], sd0["conv1.bias"], padding=1)
+    C = y1.shape[1]
+    # what the conv epilogue + slab reduce produce on each rank: [sum(y) | sum(y^2)] in fp64
+    sums = torch.cat([y1.double().sum(dim=(0, 2, 3)), (y1.double() ** 2).sum(dim=(0, 2, 3))])
+    st = BNState(training=True, C0=x.shape[1], group=dist.group.WORLD, world=WORLD)
+    _all_reduce_(sums, st)                                   # the product's exchange
+    count = float(y1.numel() // C * st.world)                # equal per-rank pixel counts (documented assumption)
+    mean = sums[:C] / count
+    var = sums[C:] / count - mean * mean
+    scale = sd0["bn1.weight"].double() / torch.sqrt(var + 1e-5)
+    shift = sd0["bn1.bias"].double() - mean * scale
+    a1 = torch.relu(y1.double() * scale[None, :, None, None] + shift[None, :, None, None]).float()
+    rm = 0.9 * sd0["bn1.running_mean"].double() + 0.1 * mean
+    rv = 0.9 * sd0["bn1.running_var"].double() + 0.1 * var * count / (count - 1)
+    torch.save({"a1": a1, "rm": rm.float(), "rv": rv.float()}, os.path.join(out_dir, f"bn_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_syncbn_exchange_world2_equals_reference_single_device(tmp_path):
+    init = tempfile.mktemp(dir=tmp_path)
+    mp.spawn(_worker_syncbn, args=(init, str(tmp_path)), nprocs=WORLD, join=True)
+    d = load_npz("g8_syncbn.npz")
+    sd0, sd1 = sub(d, "sd0"), sub(d, "sd1")
+    x = t(d["x"])
+    # reference: single device, joint batch (first half of the VGG block)
+    y1 = torch.nn.functional.conv2d(x, sd0["conv1.weight"], sd0["conv1.bias"], padding=1)
+    ref = torch.relu(torch.nn.functional.batch_norm(y1, None, None, sd0["bn1.weight"], sd0["bn1.bias"], True, 0.1, 1e-5))
+    parts = [torch.load(os.path.join(tmp_path, f"bn_{r}.pt")) for r in range(WORLD)]
+    got = torch.cat([p["a1"] for p in parts], 0)
+    assert rel_err(got, ref) < 1e-5
+    for p in parts:                                          # running stats identical on every rank == reference's
+        assert rel_err(p["rm"], sd1["bn1.running_mean"]) < 1e-5
+        assert rel_err(p["rv"], sd1["bn1.running_var"]) < 1e-5

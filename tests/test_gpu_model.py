@@ -111,19 +111,6 @@ def test_bf16_mode_full_model(mau, name):
     assert e_grad <= 1.5 * grad_yard + 2e-2
 
 
-def test_init_matches_reference_seed(mau):
-    """Same torch.manual_seed -> same initial state_dict as the reference's constructors (via the oracle)."""
-    for mt, flags in (("unet", dict(temporal_embeddings=False, metadata_embeddings=True)), ("unet++", {})):
-        torch.manual_seed(7)
-        net = mau.UrbanPredictor(mt, 6, 10, 8, 4, 8, 12, 2, base_filters=4, **flags)
-        torch.manual_seed(7)
-        ref = R.init_state(mt, 6, 10, 8, 4, 8, 12, 2, base_filters=4, **flags)
-        sd = net.state_dict()
-        assert set(sd) == set(ref)
-        for k in ref:
-            assert torch.equal(sd[k], ref[k]), k
-
-
 def test_full_size_known_answer_fp32(mau):
     """BASELINE config 1 (base_filters=64, 256x256, B=2): the reference's known-answer statistics
     (tests/golden/g7_full_summary.json) from the HIP fp32 path."""
