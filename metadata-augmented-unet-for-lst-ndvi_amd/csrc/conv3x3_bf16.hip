@@ -21,6 +21,7 @@
 //
 // Replaces nn.Conv2d(.,.,3,padding=1) + the statistics half of nn.BatchNorm2d of VGGBlock
 // (reference src/model.py:12-15).
+#include <stdlib.h>
 #include "conv_common.h"
 
 namespace mau {
@@ -47,15 +48,24 @@ __device__ __forceinline__ int perm32(int i) {
   return i < 4 ? i : i < 12 ? i + 12 : i < 16 ? i - 8 : i < 20 ? i + 8 : i < 28 ? i - 12 : i;
 }
 
-template <int BN>
+// counted wait on the vector-memory counter (LDS-DMA included); N must be a compile-time constant
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN, int NSTAGE>
 __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt) {
   constexpr int NW = BN / 16;                         // waves per workgroup
   constexpr int W_Q = 9 * BN * 2 / 64;                // wave-DMAs for the weight slab
   constexpr int TOT_Q = HALO_Q + W_Q;
   constexpr int STAGE = HALO_BYTES + W_Q * 1024;      // bytes per LDS stage
-  constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;
+  constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;     // every wave issues exactly this many DMAs per stage
+  constexpr int DUMP = NSTAGE * STAGE;                // 1 KiB dump slot for the padding DMAs
+  constexpr int DIST = NSTAGE - 1;                    // stages in flight ahead of the one being multiplied
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "2 or 3 LDS stages");
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NSTAGE * STAGE + 1 KiB
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,11 +123,12 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
       const int q = wave + j * NW;                    // wave-uniform
+      const bf16* src = zero;
+      int dst = DUMP;                                 // padding DMA (keeps the per-wave count uniform for vmcnt)
       if (q < TOT_Q) {
-        const bf16* src;
+        dst = stage * STAGE + q * 1024;
         if (q < HALO_Q) {
           const int c = c0 + src_c[j];
-          src = zero;
           if (src_base[j] != nullptr) {
             if (c < p.C0 || (p.E == 0 && c < p.ldx)) src = src_base[j] + c;
             else if (c < p.C0 + p.E) src = embn + (c - p.C0);
@@ -125,8 +136,8 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
         } else {
           src = src_base[j] + (size_t)chunk * w_stage_stride;
         }
-        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + stage * STAGE + q * 1024), 16, 0, 0);
       }
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + dst), 16, 0, 0);
     }
   };
 
@@ -150,11 +161,23 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  issue(0, 0);
-  __syncthreads();                                     // (drains the DMA: s_waitcnt vmcnt(0) + barrier)
+  // Pipeline: DIST stages are in flight ahead of the one being multiplied.  Per stage: counted wait for
+  // THIS wave's DMAs of the stage (the newer ones stay in flight) -> raw barrier (every wave's DMAs have
+  // landed, and everyone has finished reading the buffer that is refilled next) -> issue the stage
+  // DIST ahead -> multiply.  __syncthreads() is avoided on purpose: its fence would drain vmcnt to 0.
+#pragma unroll
+  for (int d = 0; d < DIST; ++d)
+    if (d < p.nChunks) issue(d, d);
   int stage = 0;
   for (int chunk = 0; chunk < p.nChunks; ++chunk) {
-    if (chunk + 1 < p.nChunks) issue(stage ^ 1, chunk + 1);
+    const int newer = min(DIST - 1, p.nChunks - 1 - chunk);      // younger stages that may stay in flight
+    if (newer >= 1) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (chunk + DIST < p.nChunks) {
+      int ns = stage + DIST;
+      if (ns >= NSTAGE) ns -= NSTAGE;
+      issue(ns, chunk + DIST);
+    }
     const unsigned char* sb = smem + stage * STAGE;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -167,9 +190,9 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
       acc[1][0] = mfma32(a1, b0, acc[1][0]);
       acc[1][1] = mfma32(a1, b1, acc[1][1]);
     }
-    __syncthreads();                                   // next stage landed; everyone is done with this one
-    stage ^= 1;
+    stage = stage + 1 == NSTAGE ? 0 : stage + 1;
   }
+  __syncthreads();                                     // everyone is done with the stage buffers (no DMA pending)
 
   // ---- epilogue ----
   bf16* stg = reinterpret_cast<bf16*>(smem) + wave * (64 * 64);      // this wave's 64 pixels x 64 channels
@@ -229,16 +252,18 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
   }
 }
 
-template <int BN>
+template <int BN, int NSTAGE>
 static int launch(const ConvP& p, hipStream_t st) {
   constexpr int W_Q = 9 * BN * 2 / 64;
   constexpr int STAGE = HALO_BYTES + W_Q * 1024;
   constexpr int NW = BN / 16;
   constexpr size_t epi = (size_t)NW * 64 * 64 * 2 + 4 * 2 * BN * sizeof(float);
-  constexpr size_t lds = 2 * STAGE > epi ? 2 * STAGE : epi;
+  constexpr size_t ring = (size_t)NSTAGE * STAGE + 1024;
+  constexpr size_t lds = ring > epi ? ring : epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int tilesX = ceil_div(p.W, TS), tilesY = ceil_div(p.H, TS);
@@ -249,7 +274,7 @@ static int launch(const ConvP& p, hipStream_t st) {
   const int nPixTiles = p.N * tilesX * tilesY;
   const int nCt = p.CoutPad / BN;
   const int grid = round_up(nPixTiles, 8) * nCt;
-  hipLaunchKernelGGL(conv3x3_bf16_kernel<BN>, dim3(grid), dim3(BN * 4), lds, st, q, nPixTiles, nCt);
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<BN, NSTAGE>), dim3(grid), dim3(BN * 4), lds, st, q, nPixTiles, nCt);
   return check_launch("conv3x3_bf16_kernel");
 }
 }  // namespace v2
@@ -257,8 +282,10 @@ static int launch(const ConvP& p, hipStream_t st) {
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W) { return N * ceil_div(H, v2::TS) * ceil_div(W, v2::TS); }
 
 int launch_conv_bf16_v2(const ConvP& p, hipStream_t st) {
-  if (p.CoutPad % 128 == 0) return v2::launch<128>(p, st);
-  return v2::launch<64>(p, st);
+  static const int stages128 = getenv("MAU_CONV_STAGES128") ? atoi(getenv("MAU_CONV_STAGES128")) : 2;
+  static const int stages64 = getenv("MAU_CONV_STAGES64") ? atoi(getenv("MAU_CONV_STAGES64")) : 2;
+  if (p.CoutPad % 128 == 0) return stages128 == 3 ? v2::launch<128, 3>(p, st) : v2::launch<128, 2>(p, st);
+  return stages64 == 3 ? v2::launch<64, 3>(p, st) : v2::launch<64, 2>(p, st);
 }
 
 }  // namespace mau

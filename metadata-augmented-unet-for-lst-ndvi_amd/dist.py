@@ -26,6 +26,18 @@ import torch
 import torch.distributed as dist
 
 
+def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
+    """SUM all-reduce of ``t`` in place.  RCCL ("nccl") reduces device tensors directly; under the
+    "gloo" rehearsal backend (CPU tests, or several ranks sharing one GPU) a device tensor is staged
+    through host memory -- correctness rehearsal only, never the measured path."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.detach().cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+        return None
+    return dist.all_reduce(t, group=group, async_op=async_op)
+
+
 class _Bucket:
     __slots__ = ("lo", "hi", "params", "pending", "handle", "launched")
 
@@ -84,7 +96,7 @@ class GradSync:
     def _launch(self, b: _Bucket):
         b.launched = True
         if self.world > 1:
-            b.handle = dist.all_reduce(self.flat[b.lo:b.hi], group=self.group, async_op=True)
+            b.handle = all_reduce_sum(self.flat[b.lo:b.hi], self.group, async_op=True)
 
     def _on_grad(self, p: torch.nn.Parameter):
         if not self._active:
@@ -133,10 +145,13 @@ def init_process_group_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("MAU_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % max(1, torch.cuda.device_count())      # rehearsal: several ranks may share one GPU
     return rank, local, world

@@ -174,8 +174,8 @@ class BNState:
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
     if st.group is not None and st.world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t, group=st.group)
+        from .dist import all_reduce_sum
+        all_reduce_sum(t, st.group)
 
 
 class ConvBNReLU(torch.autograd.Function):

@@ -1,0 +1,67 @@
+"""Rehearsal of the N>1 path on ONE GPU: two ranks share cuda:0, collectives over the gloo backend
+(staged through host memory).  Checks that 2 ranks x batch b with SyncBN + GradSync reproduce a
+single process with batch 2b, through the real module, kernels and hooks."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["MAU_ROOT"])
+import torch.distributed as dist
+import mau_amd
+from mau_amd.dist import GradSync, init_process_group_from_env
+rank, local, world = init_process_group_from_env()
+torch.cuda.set_device(local)
+torch.manual_seed(0)
+kw = dict(model_type="unet", spatial_channels=6, seq_len=10, temporal_dim=8, meta_features=4, meta_dim=8, lstm_dim=12,
+          out_channels=2, base_filters=8, temporal_embeddings=False, metadata_embeddings=True)
+net = mau_amd.UrbanPredictor(**kw).cuda().set_precision("fp32").train()
+g = torch.Generator().manual_seed(3)
+x = torch.randn(4, 6, 32, 32, generator=g); ts = torch.randn(4, 10, generator=g); md = torch.randn(4, 4, generator=g); tgt = torch.randn(4, 2, 32, 32, generator=g)
+if world > 1:
+    sl = slice(rank * 2, rank * 2 + 2)
+    x, ts, md, tgt = x[sl], ts[sl], md[sl], tgt[sl]
+    net.set_sync_bn(dist.group.WORLD)
+    sync = GradSync(net, bucket_bytes=64 << 10)
+x, ts, md, tgt = x.cuda(), ts.cuda(), md.cuda(), tgt.cuda()
+out = net(x, ts, md)
+loss = mau_amd.compute_loss_mse(out, tgt)["total"]
+if world > 1: sync.begin()
+loss.backward()
+if world > 1: sync.finish()
+torch.cuda.synchronize()
+res = {"out": out.detach().cpu(), "grads": {k: (p.grad.cpu().clone() if p.grad is not None else None) for k, p in net.named_parameters()},
+       "rm": net.model.conv0_0.bn1.running_mean.cpu(), "rv": net.model.conv2_0.bn2.running_var.cpu()}
+torch.save(res, os.path.join(os.environ["MAU_OUT"], f"res_w{world}_r{rank}.pt"))
+if world > 1: dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MAU_ROOT=ROOT, MAU_OUT=str(tmp_path), MAU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.run([sys.executable, str(script)], check=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29517", str(script)], check=True, env=env, timeout=300)
+    one = torch.load(tmp_path / "res_w1_r0.pt")
+    r0, r1 = torch.load(tmp_path / "res_w2_r0.pt"), torch.load(tmp_path / "res_w2_r1.pt")
+    out2 = torch.cat([r0["out"], r1["out"]], 0)
+    assert float((out2 - one["out"]).abs().max() / one["out"].abs().max()) < 1e-4
+    for k, gref in one["grads"].items():
+        if gref is None:
+            assert r0["grads"][k] is None
+            continue
+        assert torch.equal(r0["grads"][k], r1["grads"][k]), k            # averaged gradients identical on both ranks
+        err = float((r0["grads"][k] - gref).abs().max() / gref.abs().max().clamp_min(1e-12))
+        assert err < 2e-3 or float((r0["grads"][k] - gref).abs().max()) < 1e-6, (k, err)
+    for key in ("rm", "rv"):
+        assert float((r0[key] - one[key]).abs().max() / one[key].abs().max()) < 1e-4
+        assert torch.equal(r0[key], r1[key])
