@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--model-type", default="unet", choices=["unet", "unet++"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--infer", action="store_true", help="inference-only images/s (eval mode, no_grad): BASELINE configs[4]")
+    ap.add_argument("--channels", type=int, default=6, help="input channels (6 = BASELINE configs, 23 = the app's real shape)")
+    ap.add_argument("--meta", type=int, default=4)
     ap.add_argument("--no-sync-bn", action="store_true", help="per-GPU BatchNorm statistics (reference semantics per device)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/)")
@@ -123,13 +126,13 @@ def main():
     # ---- model / synthetic data --------------------------------------------------
     torch.manual_seed(0)                       # identical replicas on every rank
     flags = {} if args.model_type == "unet++" else dict(temporal_embeddings=False, metadata_embeddings=True)
-    net = mau_amd.UrbanPredictor(args.model_type, 6, 10, 64, 4, 64, 96, 2, base_filters=64, **flags)
+    net = mau_amd.UrbanPredictor(args.model_type, args.channels, 10, 64, args.meta, 64, 96, 2, base_filters=64, **flags)
     net = net.to(dev).set_precision(args.precision).train()
     g = torch.Generator().manual_seed(1234 + rank)
     B, S = args.batch, args.size
-    x = torch.randn(B, 6, S, S, generator=g).to(dev)
+    x = torch.randn(B, args.channels, S, S, generator=g).to(dev)
     ts = torch.randn(B, 10, generator=g).to(dev)
-    md = torch.randn(B, 4, generator=g).to(dev)
+    md = torch.randn(B, args.meta, generator=g).to(dev)
     tgt = torch.randn(B, 2, S, S, generator=g).to(dev)
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-3, fused=True)   # conf/config.yaml:41,48,52
     sync = None
@@ -139,7 +142,13 @@ def main():
         sync = GradSync(net, dist.group.WORLD)
     losses = torch.zeros(args.steps + args.warmup, device=dev)
 
+    def infer_step(i):
+        with torch.no_grad():
+            net(x, ts, md)
+
     def step(i):
+        if args.infer:
+            return infer_step(i)
         out = net(x, ts, md)
         loss = mau_amd.compute_loss_mse(out, tgt)["total"]
         if sync is not None:
@@ -151,6 +160,8 @@ def main():
         opt.zero_grad()
         losses[i] = loss.detach()
 
+    if args.infer:
+        net.eval()
     timer = ConvTimer(F_)
     timer.install()
 
@@ -203,7 +214,7 @@ def main():
                 "flop_per_launch_avg": conv["total_flop"] / conv["launches"],
                 "share_of_step_time": round(conv["total_ms"] / (elapsed * 1e3), 4)}
     result = {
-        "metric": "train images/sec (256x256x6->2 U-Net, B=32/GPU)" if args.model_type == "unet" else "train images/sec (U-Net++)",
+        "metric": ("inference images/sec" if args.infer else "train images/sec") + f" ({S}x{S}x{args.channels}->2 {'U-Net' if args.model_type == 'unet' else 'U-Net++'}, B={B}/GPU)",
         "value": round(B * world * args.steps / elapsed, 2),
         "unit": "images/s",
         "n_gpus": world,
@@ -215,8 +226,8 @@ def main():
         "vs_baseline": None,
         "dtype": args.precision,
         "data": "synthetic",
-        "config": {"workload": f"metadata-{args.model_type} base_filters=64, {B}x6x{S}x{S} tiles + 4-dim metadata per GPU, "
-                               "fwd+MSE+bwd+AdamW (src/train.py:243-256), BASELINE configs[1]",
+        "config": {"workload": (f"metadata-{args.model_type} base_filters=64, {B}x{args.channels}x{S}x{S} tiles + {args.meta}-dim metadata per GPU, "
+                                + ("eval-mode forward only (inference)" if args.infer else "fwd+MSE+bwd+AdamW (src/train.py:243-256)")),
                    "global_batch": B * world, "parallelism": f"dp{world}",
                    "sync_bn": bool(world > 1 and not args.no_sync_bn)},
         "fwd_ms_per_tile": round(fwd_ms_per_tile, 4),
