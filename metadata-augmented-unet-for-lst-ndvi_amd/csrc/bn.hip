@@ -128,7 +128,20 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
       sc[j] = ok ? scale[c + j] : 0.f;
       sh[j] = ok ? shift[c + j] : 0.f;
     }
-    for (int64_t pix = p0 + m.ps; pix < p1; pix += m.PS) {
+    int64_t pix = p0 + m.ps;
+    for (; pix + 3 * m.PS < p1; pix += 4 * m.PS) {          // 4 independent 16-byte loads in flight per lane
+      F8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = load8<T>(y + (pix + u * m.PS) * ldy + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        F8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = fmaxf(fmaf(v[u].v[j], sc[j], sh[j]), 0.f);
+        store8<T>(a + (pix + u * m.PS) * lda + c, o);
+      }
+    }
+    for (; pix < p1; pix += m.PS) {
       const F8 v = load8<T>(y + pix * ldy + c);
       F8 o;
 #pragma unroll
@@ -165,7 +178,25 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
     is[j] = ok ? invstd[cc] : 0.f;
   }
   if (c0 < C) {
-    for (int64_t p = p0 + ps; p < p1; p += 32) {
+    int64_t p = p0 + ps;
+    for (; p + 32 < p1; p += 64) {                           // 4 independent 16-byte loads in flight per lane
+      F8 g[2], v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        g[u] = load8<T>(da + (p + 32 * u) * ldda + c0);
+        v[u] = load8<T>(y + (p + 32 * u) * ldy + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float act = fmaf(v[u].v[j], sc[j], sh[j]);
+          const float dz = act > 0.f ? g[u].v[j] : 0.f;
+          s1[j] += dz;
+          s2[j] += dz * ((v[u].v[j] - mu[j]) * is[j]);
+        }
+    }
+    for (; p < p1; p += 32) {
       const F8 g = load8<T>(da + p * ldda + c0);
       const F8 v = load8<T>(y + p * ldy + c0);
 #pragma unroll
@@ -220,7 +251,27 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
       k1[j] = sc[j] * m2 * is;
       k0[j] = sc[j] * m1 - k1[j] * mu;
     }
-    for (int64_t pix = p0 + m.ps; pix < p1; pix += m.PS) {
+    int64_t pix = p0 + m.ps;
+    for (; pix + 3 * m.PS < p1; pix += 4 * m.PS) {          // 8 independent 16-byte loads in flight per lane
+      F8 g[4], v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = load8<T>(da + (pix + u * m.PS) * ldda + c);
+        v[u] = load8<T>(y + (pix + u * m.PS) * ldy + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        F8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float act = fmaf(v[u].v[j], sc[j], sh[j]);
+          const float dz = act > 0.f ? g[u].v[j] : 0.f;
+          o.v[j] = fmaf(sc[j], dz, -fmaf(k1[j], v[u].v[j], k0[j]));
+        }
+        store8<T>(dy + (pix + u * m.PS) * lddy + c, o);
+      }
+    }
+    for (; pix < p1; pix += m.PS) {
       const F8 g = load8<T>(da + pix * ldda + c);
       const F8 v = load8<T>(y + pix * ldy + c);
       F8 o;
