@@ -179,17 +179,39 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
       issue(ns, chunk + DIST);
     }
     const unsigned char* sb = smem + stage * STAGE;
+    // register double-buffered operands: the reads of tap t+1 are issued before the MFMAs of tap t, so the
+    // compiler's LDS waits become counted (lgkmcnt(4)) instead of draining to 0 in front of every MFMA group
+    bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sb + aoff[0][0]);
+    bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sb + aoff[1][0]);
+    bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + boff0);
+    bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + boff1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sb + aoff[0][tap]);
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sb + aoff[1][tap]);
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + boff0 + tap * BN * ROWB);
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + boff1 + tap * BN * ROWB);
+      bf16x8 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+      if (tap < 8) {
+        na0 = *reinterpret_cast<const bf16x8*>(sb + aoff[0][tap + 1]);
+        na1 = *reinterpret_cast<const bf16x8*>(sb + aoff[1][tap + 1]);
+        nb0 = *reinterpret_cast<const bf16x8*>(sb + boff0 + (tap + 1) * BN * ROWB);
+        nb1 = *reinterpret_cast<const bf16x8*>(sb + boff1 + (tap + 1) * BN * ROWB);
+      }
       acc[0][0] = mfma32(a0, b0, acc[0][0]);
       acc[0][1] = mfma32(a0, b1, acc[0][1]);
       acc[1][0] = mfma32(a1, b0, acc[1][0]);
       acc[1][1] = mfma32(a1, b1, acc[1][1]);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
+    // pin the interleave in the emitted code (LLVM SchedGroupMask: 0x100 = DS read, 0x008 = MFMA):
+    // 4 reads of tap 0, then per tap {1 MFMA of tap t, 1 read of tap t+1} x 4; the last tap is MFMA only.
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int tap = 0; tap < 8; ++tap) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     stage = stage + 1 == NSTAGE ? 0 : stage + 1;
   }
   __syncthreads();                                     // everyone is done with the stage buffers (no DMA pending)

@@ -10,6 +10,7 @@ fuse_embeddings :248-259, head :284-292), src/utils/losses.py:27-39.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -178,6 +179,17 @@ def _all_reduce_(t: torch.Tensor, st: BNState):
         all_reduce_sum(t, st.group)
 
 
+_OVERLAP_WGRAD = os.environ.get("MAU_OVERLAP_WGRAD", "0") != "0"      # measured: ~1 % (profiles/r1), off by default
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
 class ConvBNReLU(torch.autograd.Function):
     """relu(bn(conv3x3(cat([x, broadcast(emb)])))) -- one half of VGGBlock.forward (src/model.py:18-21)."""
 
@@ -267,19 +279,26 @@ class ConvBNReLU(torch.autograd.Function):
         dy = torch.empty_like(y)
         call("mau_bn_relu_bwd_apply", da.data_ptr(), _ld(da), y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(),
              mean.data_ptr(), invstd.data_ptr(), sums_apply.data_ptr(), count, dy.data_ptr(), ldy, code, npix, Cout, stream)
-        # --- weight gradient ---
+        # --- weight gradient: independent of the data gradient given dy -> runs on a side stream so the two
+        #     kernels (often only 256-512 workgroups each) fill each other's tails; joined before returning ---
         dw = None
+        need_dx = ctx.needs_input_grad[0] or (E and ctx.needs_input_grad[1])
+        side = _side_stream(dev) if (ctx.needs_input_grad[2] and need_dx and _OVERLAP_WGRAD) else None
         if ctx.needs_input_grad[2]:
             acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), **f32)
             emb_ws = torch.empty((N, E), dtype=y.dtype, device=dev) if E else None
-            call("mau_conv3x3_wgrad", x.data_ptr(), _ld(x), st.C0, emb.data_ptr() if E else None,
-                 emb_ws.data_ptr() if E else None, E, dy.data_ptr(), ldy, Cout, acc.data_ptr(), code, N, H, W, stream)
             dw = torch.empty_like(weight)
+            wstream = stream
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                wstream = side.cuda_stream
+            call("mau_conv3x3_wgrad", x.data_ptr(), _ld(x), st.C0, emb.data_ptr() if E else None,
+                 emb_ws.data_ptr() if E else None, E, dy.data_ptr(), ldy, Cout, acc.data_ptr(), code, N, H, W, wstream)
             call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin),
-                 dw.data_ptr(), Cout, Cin, stream)
+                 dw.data_ptr(), Cout, Cin, wstream)
         # --- data gradient (same implicit-GEMM kernel, rotated/transposed weight pack) ---
         dx = demb = None
-        if ctx.needs_input_grad[0] or (E and ctx.needs_input_grad[1]):
+        if need_dx:
             wd = PACK_CACHE.get(weight, code, "d")
             ldd = pad8(Cin)
             dfull = torch.empty((N, H, W, ldd), dtype=y.dtype, device=dev)
@@ -293,6 +312,8 @@ class ConvBNReLU(torch.autograd.Function):
                     dx = dfull[..., :pad8(st.C0)]            # C0 % 8 == 0 is enforced by the kernel when E > 0
             else:
                 dx = dfull
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         # conv bias followed by train-mode BN has an identically zero gradient (the batch mean absorbs it)
         dbias = torch.zeros(Cout, **f32) if ctx.needs_input_grad[3] else None
         return dx, demb, dw, dbias, dgamma, dbeta, None, None, None, None
