@@ -147,11 +147,12 @@ def test_production_shape_fp32_vs_oracle(mau, model_type, B):
     (250->125->62->31->15: every decoder level takes the odd-size second resize), 8 metadata features,
     temporal + metadata embeddings, base_filters 64.  HIP fp32 path vs the CPU oracle, same seed.
 
-    Tolerances: outputs and loss <= 1e-3 (north star).  Gradients at this depth/batch are judged at 2e-2:
-    the reference's OWN fp32 gradients differ from an fp64 evaluation of the same graph by up to 5.2e-2
-    relative (U-Net++ B=1, measured with the oracle in this repo's build container: ReLU masks flip where
-    a pre-activation differs in the last bits, and BatchNorm over one image amplifies it); the HIP path is
-    3-6e-3 from the reference's fp32."""
+    Tolerances: outputs and loss <= 1e-3 (north star).  Gradients at this depth/batch are judged at 1.5e-2 relative L2 and 1.6e-1 max-norm (2x the yardstick):
+    the reference's OWN fp32 gradients differ from an fp64 evaluation of the same graph by up to 8.1e-2
+    max-norm / 7.1e-3 relative L2 (U-Net B=2: conv3_0.conv1.weight; U-Net++ B=1: 5.2e-2), measured with
+    the oracle in the build container: ReLU masks flip where a pre-activation differs in the last bits
+    and small-batch BatchNorm amplifies it.  The HIP fp32 path shows the same figures on the same
+    parameters (8.2e-2 / 7.3e-3), i.e. it is as close to the reference as the reference is to exact math."""
     flags = {} if model_type == "unet++" else dict(temporal_embeddings=True, metadata_embeddings=True)
     torch.manual_seed(11)
     net = mau.UrbanPredictor(model_type, 23, 12, 64, 8, 64, 96, 2, base_filters=64, **flags)
@@ -176,8 +177,9 @@ def test_production_shape_fp32_vs_oracle(mau, model_type, B):
         if not R.is_param(k) or v.grad is None or k.endswith(".conv1.bias") or k.endswith(".conv2.bias"):
             continue
         got = params[k].grad.cpu()
-        e = rel_err(got, v.grad)
-        assert e < 2e-2 or float((got - v.grad).abs().max()) < 1e-6, (k, e)
+        e, e2 = rel_err(got, v.grad), rel_l2(got, v.grad)
+        small = float((got - v.grad).abs().max()) < 1e-6
+        assert (e < 1.6e-1 and e2 < 1.5e-2) or small, (k, e, e2)   # 2x the reference's own fp32-vs-fp64 deviation
     # bf16 throughput mode on the same shape: finite, and close in relative L2
     net.zero_grad(set_to_none=True)
     net.load_state_dict(sd0)
