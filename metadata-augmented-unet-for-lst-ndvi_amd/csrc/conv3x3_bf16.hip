@@ -54,81 +54,106 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, int NSTAGE>
-__global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt) {
+// One (pixel tile, cout tile) work item.
+struct Item {
+  int pixTile, n, ty0, tx0, co0;
+};
+
+template <int BN>
+__global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
   constexpr int NW = BN / 16;                         // waves per workgroup
   constexpr int W_Q = 9 * BN * 2 / 64;                // wave-DMAs for the weight slab
   constexpr int TOT_Q = HALO_Q + W_Q;
   constexpr int STAGE = HALO_BYTES + W_Q * 1024;      // bytes per LDS stage
-  constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;     // every wave issues exactly this many DMAs per stage
-  constexpr int DUMP = NSTAGE * STAGE;                // 1 KiB dump slot for the padding DMAs
-  constexpr int DIST = NSTAGE - 1;                    // stages in flight ahead of the one being multiplied
-  static_assert(NSTAGE == 2 || NSTAGE == 3, "2 or 3 LDS stages");
+  constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;     // DMAs per wave per stage
+  constexpr int RED_OFF = 2 * STAGE;                  // [4 wm][2][BN] floats for the BatchNorm partials
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NSTAGE * STAGE + 1 KiB
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE + red
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;            // 4 (pixel rows) x BN/64 (channels)
   const int i32 = perm32(lane & 31), h = lane >> 5;   // tile row (pixel / channel) this lane's operands come from
 
-  // ---- XCD-aware block -> (pixel tile, cout tile) map ----
-  const int P = blockIdx.x;
-  const int xcd = P & 7, seq = P >> 3;
-  const int pixTile = xcd + 8 * (seq / nCt);
-  const int ct = seq % nCt;
-  if (pixTile >= nPixTiles) return;                   // whole workgroup leaves before any barrier
-  int t = pixTile;
-  const int txi = t % p.tilesX;
-  t /= p.tilesX;
-  const int tyi = t % p.tilesY;
-  const int n = t / p.tilesY;
-  const int ty0 = tyi * TS, tx0 = txi * TS;
-  const int co0 = ct * BN;
-
   const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(p.x);
   const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(p.w);
-  const bf16* __restrict__ embn = reinterpret_cast<const bf16*>(p.emb_lp) + (size_t)n * p.E;
   const bf16* zero = reinterpret_cast<const bf16*>(g_zero_page);
 
-  // ---- per-lane source descriptors of this wave's DMAs (constant over stages) ----
-  const bf16* src_base[PER_WAVE];   // halo: pixel base (channel 0) or nullptr when outside the image; weights: row base
-  int src_c[PER_WAVE];              // halo: 8 * logical half;  weights: unused
+  // ---- work items: XCD-aware order; a persistent workgroup walks I = blockIdx.x, +gridDim.x, ...
+  // (gridDim.x is a multiple of 8, so a workgroup stays on one XCD's slice of the item list) ----
+  auto decode = [&](int I, Item& it) -> bool {
+    const int xcd = I & 7, seq = I >> 3;
+    it.pixTile = xcd + 8 * (seq / nCt);
+    if (it.pixTile >= nPixTiles) return false;
+    it.co0 = (seq % nCt) * BN;
+    int t = it.pixTile;
+    const int txi = t % p.tilesX;
+    t /= p.tilesX;
+    const int tyi = t % p.tilesY;
+    it.n = t / p.tilesY;
+    it.ty0 = tyi * TS;
+    it.tx0 = txi * TS;
+    return true;
+  };
+  auto next_valid = [&](int I, Item& it) -> int {
+    for (; I < nItems; I += gridDim.x)
+      if (decode(I, it)) return I;
+    return -1;
+  };
+
+  // ---- per-lane DMA slots: the tile-independent part ----
+  int slot_hp[PER_WAVE];            // halo: pixel index inside the halo tile (or -1); weights: row = tap*BN + co
+  int slot_c[PER_WAVE];             // 8 * logical 16-byte half
 #pragma unroll
   for (int j = 0; j < PER_WAVE; ++j) {
     const int q = wave + j * NW;
-    src_base[j] = nullptr;
-    src_c[j] = 0;
+    slot_hp[j] = -1;
+    slot_c[j] = 0;
     if (q < HALO_Q) {
       const int slot = q * 64 + lane;
       const int hp = slot >> 1, ph = slot & 1;
-      const int lh = ph ^ ((hp >> 3) & 1);
-      src_c[j] = 8 * lh;
-      if (hp < HPIX) {
-        const int gy = ty0 + hp / HS - 1, gx = tx0 + hp % HS - 1;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) src_base[j] = xg + ((size_t)(n * p.H + gy) * p.W + gx) * (size_t)p.ldx;
-      }
+      slot_c[j] = 8 * (ph ^ ((hp >> 3) & 1));
+      slot_hp[j] = hp < HPIX ? hp : -1;
     } else if (q < TOT_Q) {
       const int slot = (q - HALO_Q) * 64 + lane;
-      const int row = slot >> 1, ph = slot & 1;       // row = tap * BN + co
-      const int lh = ph ^ ((row >> 3) & 1);
-      const int tap = row / BN, co = row % BN;
-      src_base[j] = wg + ((size_t)tap * p.CoutPad + co0 + co) * KC + 8 * lh;
+      const int row = slot >> 1, ph = slot & 1;
+      slot_c[j] = 8 * (ph ^ ((row >> 3) & 1));
+      slot_hp[j] = row;
     }
   }
   const size_t w_stage_stride = (size_t)9 * p.CoutPad * KC;
 
+  // source descriptors of the item being LOADED (constant over its stages)
+  const bf16* src_base[PER_WAVE];
+  const bf16* embn = nullptr;
+  auto setup = [&](const Item& it) {
+    embn = reinterpret_cast<const bf16*>(p.emb_lp) + (size_t)it.n * p.E;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+      const int q = wave + j * NW;
+      src_base[j] = nullptr;
+      if (q < HALO_Q) {
+        const int hp = slot_hp[j];
+        if (hp >= 0) {
+          const int gy = it.ty0 + hp / HS - 1, gx = it.tx0 + hp % HS - 1;
+          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) src_base[j] = xg + ((size_t)(it.n * p.H + gy) * p.W + gx) * (size_t)p.ldx;
+        }
+      } else if (q < TOT_Q) {
+        const int row = slot_hp[j];
+        const int tap = row / BN, co = row % BN;
+        src_base[j] = wg + ((size_t)tap * p.CoutPad + it.co0 + co) * KC + slot_c[j];
+      }
+    }
+  };
   auto issue = [&](int stage, int chunk) {
     const int c0 = chunk * KC;
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
       const int q = wave + j * NW;                    // wave-uniform
-      const bf16* src = zero;
-      int dst = DUMP;                                 // padding DMA (keeps the per-wave count uniform for vmcnt)
       if (q < TOT_Q) {
-        dst = stage * STAGE + q * 1024;
+        const bf16* src = zero;
         if (q < HALO_Q) {
-          const int c = c0 + src_c[j];
+          const int c = c0 + slot_c[j];
           if (src_base[j] != nullptr) {
             if (c < p.C0 || (p.E == 0 && c < p.ldx)) src = src_base[j] + c;
             else if (c < p.C0 + p.E) src = embn + (c - p.C0);
@@ -136,12 +161,12 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
         } else {
           src = src_base[j] + (size_t)chunk * w_stage_stride;
         }
+        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + stage * STAGE + q * 1024), 16, 0, 0);
       }
-      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + dst), 16, 0, 0);
     }
   };
 
-  // ---- per-lane LDS read offsets (constant over stages) ----
+  // ---- per-lane LDS read offsets (constant) ----
   int aoff[2][9];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -153,139 +178,161 @@ __global__ __launch_bounds__(BN * 4) void conv3x3_bf16_kernel(ConvP p, int nPixT
   const int boff0 = HALO_BYTES + swz_off(wn * 64 + i32, h);          // (tap*BN is a multiple of 16 rows: swizzle unchanged)
   const int boff1 = HALO_BYTES + swz_off(wn * 64 + 32 + i32, h);
 
-  f32x16 acc[2][2];
+  // accumulator register r of lane half h holds MFMA row (r&3) + 8*(r>>2) + 4*h, i.e. tile row
+  // perm32(that) = rowbase[r>>2] + (r&3): four per-lane bases + immediates address the whole epilogue
+  int rowbase[4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  for (int g = 0; g < 4; ++g) rowbase[g] = perm32(8 * g + 4 * h);
 
-  // Pipeline: DIST stages are in flight ahead of the one being multiplied.  Per stage: counted wait for
-  // THIS wave's DMAs of the stage (the newer ones stay in flight) -> raw barrier (every wave's DMAs have
-  // landed, and everyone has finished reading the buffer that is refilled next) -> issue the stage
-  // DIST ahead -> multiply.  __syncthreads() is avoided on purpose: its fence would drain vmcnt to 0.
-#pragma unroll
-  for (int d = 0; d < DIST; ++d)
-    if (d < p.nChunks) issue(d, d);
+  Item cur, nxt;
+  int I = next_valid(blockIdx.x, cur);
+  if (I < 0) return;                                  // whole workgroup leaves before any barrier
+  setup(cur);
+  issue(0, 0);
   int stage = 0;
-  for (int chunk = 0; chunk < p.nChunks; ++chunk) {
-    const int newer = min(DIST - 1, p.nChunks - 1 - chunk);      // younger stages that may stay in flight
-    if (newer >= 1) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (chunk + DIST < p.nChunks) {
-      int ns = stage + DIST;
-      if (ns >= NSTAGE) ns -= NSTAGE;
-      issue(ns, chunk + DIST);
-    }
-    const unsigned char* sb = smem + stage * STAGE;
-    // register double-buffered operands: the reads of tap t+1 are issued before the MFMAs of tap t, so the
-    // compiler's LDS waits become counted (lgkmcnt(4)) instead of draining to 0 in front of every MFMA group
-    bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sb + aoff[0][0]);
-    bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sb + aoff[1][0]);
-    bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + boff0);
-    bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + boff1);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      bf16x8 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-      if (tap < 8) {
-        na0 = *reinterpret_cast<const bf16x8*>(sb + aoff[0][tap + 1]);
-        na1 = *reinterpret_cast<const bf16x8*>(sb + aoff[1][tap + 1]);
-        nb0 = *reinterpret_cast<const bf16x8*>(sb + boff0 + (tap + 1) * BN * ROWB);
-        nb1 = *reinterpret_cast<const bf16x8*>(sb + boff1 + (tap + 1) * BN * ROWB);
-      }
-      acc[0][0] = mfma32(a0, b0, acc[0][0]);
-      acc[0][1] = mfma32(a0, b1, acc[0][1]);
-      acc[1][0] = mfma32(a1, b0, acc[1][0]);
-      acc[1][1] = mfma32(a1, b1, acc[1][1]);
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-    }
-    // pin the interleave in the emitted code (LLVM SchedGroupMask: 0x100 = DS read, 0x008 = MFMA):
-    // 4 reads of tap 0, then per tap {1 MFMA of tap t, 1 read of tap t+1} x 4; the last tap is MFMA only.
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int tap = 0; tap < 8; ++tap) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    stage = stage + 1 == NSTAGE ? 0 : stage + 1;
-  }
-  __syncthreads();                                     // everyone is done with the stage buffers (no DMA pending)
+  bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
+  float* red = reinterpret_cast<float*>(smem + RED_OFF);
 
-  // ---- epilogue ----
-  bf16* stg = reinterpret_cast<bf16*>(smem) + wave * (64 * 64);      // this wave's 64 pixels x 64 channels
-  float* red = reinterpret_cast<float*>(smem + NW * 64 * 64 * 2);    // [4 wm][2][BN]
-  float s[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
+  while (true) {
+    const int In = next_valid(I + gridDim.x, nxt);
+    f32x16 acc[2][2];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int co = co0 + wn * 64 + nt * 32 + i32;
-    const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- K loop.  Per stage: wait for this wave's DMAs -> raw barrier (every wave's DMAs have landed and
+    // everyone is done with the buffer that is refilled next) -> issue the following stage, which may
+    // already belong to the NEXT work item (cross-tile pipelining) -> multiply. ----
+    for (int chunk = 0; chunk < p.nChunks; ++chunk) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (chunk + 1 < p.nChunks) {
+        issue(stage ^ 1, chunk + 1);
+      } else if (In >= 0) {
+        setup(nxt);
+        issue(stage ^ 1, 0);
+      }
+      const unsigned char* sb = smem + stage * STAGE;
+      bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sb + aoff[0][0]);
+      bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sb + aoff[1][0]);
+      bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + boff0);
+      bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + boff1);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        bf16x8 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+        if (tap < 8) {
+          na0 = *reinterpret_cast<const bf16x8*>(sb + aoff[0][tap + 1]);
+          na1 = *reinterpret_cast<const bf16x8*>(sb + aoff[1][tap + 1]);
+          nb0 = *reinterpret_cast<const bf16x8*>(sb + boff0 + (tap + 1) * BN * ROWB);
+          nb1 = *reinterpret_cast<const bf16x8*>(sb + boff1 + (tap + 1) * BN * ROWB);
+        }
+        acc[0][0] = mfma32(a0, b0, acc[0][0]);
+        acc[0][1] = mfma32(a0, b1, acc[0][1]);
+        acc[1][0] = mfma32(a1, b0, acc[1][0]);
+        acc[1][1] = mfma32(a1, b1, acc[1][1]);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      }
+      // pin the interleave (LLVM SchedGroupMask: 0x100 = DS read, 0x008 = MFMA): 4 reads of tap 0, then
+      // per tap {1 MFMA of tap t, 1 read of tap t+1} x 4; the last tap is MFMA only.
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int tap = 0; tap < 8; ++tap) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      stage ^= 1;
+    }
+
+    // ---- epilogue of `cur` (the next item's first stage is already in flight into buffer `stage`) ----
+    __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer stage^1 -> reuse it
+    bf16* stg = reinterpret_cast<bf16*>(smem + (stage ^ 1) * STAGE) + wave * (32 * 64);   // wave-private 32 px x 64 ch
+    float s[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
+    float bv[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int co = cur.co0 + wn * 64 + nt * 32 + i32;
+      bv[nt] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+    }
+    const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
+    // validity of this lane's accumulator rows: tile row rowbase[g] + k lies at (y = rowbase[g]>>4 (+2*mt), x = (rowbase[g]&15) + k)
+    int xlim[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xlim[g] = p.W - cur.tx0 - (rowbase[g] & 15);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int prow = perm32(acc_row(r, h));
-        const int pw = mt * 32 + prow;                               // pixel inside the wave tile
-        const int gy = ty0 + wm * 4 + (pw >> 4), gx = tx0 + (pw & 15);
-        const float v = acc[mt][nt][r] + bv;
-        if (gy < p.H && gx < p.W) {
-          s[nt] += v;
-          q2[nt] += v * v;
+      for (int g = 0; g < 4; ++g) {
+        const bool yok = cur.ty0 + wm * 4 + mt * 2 + (rowbase[g] >> 4) < p.H;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool ok = yok && k < xlim[g];
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const float v = acc[mt][nt][g * 4 + k] + bv[nt];
+            if (ok) {
+              s[nt] += v;
+              q2[nt] += v * v;
+            }
+            stg[(rowbase[g] + k) * 64 + nt * 32 + i32] = (bf16)v;
+          }
         }
-        stg[pw * 64 + nt * 32 + i32] = (bf16)v;
       }
-    }
-  }
-  if (p.slab != nullptr) {
+      // whole 128-byte rows: lane (pixel = pass*8 + lane/8, 16-byte vector = lane%8); wave-private LDS,
+      // DS operations of one wave execute in order -> no barrier needed between the writes and these reads
+      if (cv < p.ldy) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      s[nt] += __shfl_xor(s[nt], 32);
-      q2[nt] += __shfl_xor(q2[nt], 32);
-      if (h == 0) {
-        red[(wm * 2 + 0) * BN + wn * 64 + nt * 32 + i32] = s[nt];
-        red[(wm * 2 + 1) * BN + wn * 64 + nt * 32 + i32] = q2[nt];
+        for (int pass = 0; pass < 4; ++pass) {
+          const int prow = pass * 8 + (lane >> 3);
+          const int pw = mt * 32 + prow;
+          const int gy = cur.ty0 + wm * 4 + (pw >> 4), gx = cur.tx0 + (pw & 15);
+          if (gy < p.H && gx < p.W) {
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + prow * 64 + (lane & 7) * 8);
+            *reinterpret_cast<uint4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv) = v;
+          }
+        }
       }
     }
-  }
-  __syncthreads();
-  if (p.slab != nullptr && tid < 2 * BN) {
-    const int which = tid / BN, c = tid % BN;
-    const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c] + red[(2 * 2 + which) * BN + c] +
-                    red[(3 * 2 + which) * BN + c];
-    p.slab[((size_t)pixTile * 2 + which) * p.CoutPad + co0 + c] = v;
-  }
-  // whole 128-byte rows: lane (pixel = pass*8 + lane/8, 16-byte vector = lane%8)
-  bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
-  const int cv = co0 + wn * 64 + (lane & 7) * 8;
-  if (cv < p.ldy) {
+    if (p.slab != nullptr) {
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      const int pw = pass * 8 + (lane >> 3);
-      const int gy = ty0 + wm * 4 + (pw >> 4), gx = tx0 + (pw & 15);
-      if (gy < p.H && gx < p.W) {
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + pw * 64 + (lane & 7) * 8);
-        *reinterpret_cast<uint4*>(yg + ((size_t)(n * p.H + gy) * p.W + gx) * p.ldy + cv) = v;
+      for (int nt = 0; nt < 2; ++nt) {
+        s[nt] += __shfl_xor(s[nt], 32);
+        q2[nt] += __shfl_xor(q2[nt], 32);
+        if (h == 0) {
+          red[(wm * 2 + 0) * BN + wn * 64 + nt * 32 + i32] = s[nt];
+          red[(wm * 2 + 1) * BN + wn * 64 + nt * 32 + i32] = q2[nt];
+        }
+      }
+      __syncthreads();                                 // (no DMA of this wave can be pending past the K loop's waits
+                                                       //  except the next item's first stage: draining it here is harmless)
+      if (tid < 2 * BN) {
+        const int which = tid / BN, c = tid % BN;
+        const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c] + red[(2 * 2 + which) * BN + c] +
+                        red[(3 * 2 + which) * BN + c];
+        p.slab[((size_t)cur.pixTile * 2 + which) * p.CoutPad + cur.co0 + c] = v;
       }
     }
+    if (In < 0) break;
+    cur = nxt;
+    I = In;
   }
 }
 
-template <int BN, int NSTAGE>
+template <int BN>
 static int launch(const ConvP& p, hipStream_t st) {
   constexpr int W_Q = 9 * BN * 2 / 64;
   constexpr int STAGE = HALO_BYTES + W_Q * 1024;
-  constexpr int NW = BN / 16;
-  constexpr size_t epi = (size_t)NW * 64 * 64 * 2 + 4 * 2 * BN * sizeof(float);
-  constexpr size_t ring = (size_t)NSTAGE * STAGE + 1024;
-  constexpr size_t lds = ring > epi ? ring : epi;
+  constexpr size_t lds = 2 * (size_t)STAGE + 4 * 2 * BN * sizeof(float);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int tilesX = ceil_div(p.W, TS), tilesY = ceil_div(p.H, TS);
@@ -295,8 +342,12 @@ static int launch(const ConvP& p, hipStream_t st) {
   q.nChunks = ceil_div(p.C0 + p.E, KC);
   const int nPixTiles = p.N * tilesX * tilesY;
   const int nCt = p.CoutPad / BN;
-  const int grid = round_up(nPixTiles, 8) * nCt;
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<BN, NSTAGE>), dim3(grid), dim3(BN * 4), lds, st, q, nPixTiles, nCt);
+  const int nItems = round_up(nPixTiles, 8) * nCt;
+  // persistent: as many workgroups as fit the chip at once (BN = 64: two per CU, BN = 128: one per CU)
+  static const int per_cu = getenv("MAU_CONV_WG_PER_CU") ? atoi(getenv("MAU_CONV_WG_PER_CU")) : (BN == 64 ? 2 : 1);
+  int grid = 256 * per_cu;
+  if (grid > nItems) grid = nItems;                    // nItems is a multiple of 8, and so is 256*per_cu
+  hipLaunchKernelGGL(conv3x3_bf16_kernel<BN>, dim3(grid), dim3(BN * 4), lds, st, q, nPixTiles, nCt, nItems);
   return check_launch("conv3x3_bf16_kernel");
 }
 }  // namespace v2
@@ -304,10 +355,8 @@ static int launch(const ConvP& p, hipStream_t st) {
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W) { return N * ceil_div(H, v2::TS) * ceil_div(W, v2::TS); }
 
 int launch_conv_bf16_v2(const ConvP& p, hipStream_t st) {
-  static const int stages128 = getenv("MAU_CONV_STAGES128") ? atoi(getenv("MAU_CONV_STAGES128")) : 2;
-  static const int stages64 = getenv("MAU_CONV_STAGES64") ? atoi(getenv("MAU_CONV_STAGES64")) : 2;
-  if (p.CoutPad % 128 == 0) return stages128 == 3 ? v2::launch<128, 3>(p, st) : v2::launch<128, 2>(p, st);
-  return stages64 == 3 ? v2::launch<64, 3>(p, st) : v2::launch<64, 2>(p, st);
+  if (p.CoutPad % 128 == 0) return v2::launch<128>(p, st);
+  return v2::launch<64>(p, st);
 }
 
 }  // namespace mau
