@@ -61,7 +61,9 @@ def _exact_int_case(g, N, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (1, 8, 64, 31, 17)])
+@pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (1, 8, 64, 31, 17),
+                                   (1, 3, 5, 2, 3), (4, 8, 8, 3, 3), (2, 17, 70, 5, 40), (1, 64, 64, 16, 16), (9, 1, 1, 1, 1),
+                                   (3, 200, 72, 20, 34)])
 def test_conv3x3_exact_integers(mau, dt, shape):
     """Small-integer data is exact in bf16 and fp32: the MFMA operand/accumulator lane maps, halo
     handling and edge masking must reproduce torch's conv2d bit for bit (asymmetric weights)."""
@@ -88,14 +90,17 @@ def test_conv3x3_exact_integers(mau, dt, shape):
         assert torch.equal(got, ref.bfloat16().float())
     assert float(y[..., Cout:].float().abs().sum()) == 0.0
     # fused BatchNorm partial statistics (fp32 accumulators, before the output rounding)
-    s = slab.sum(0).cpu()
-    assert torch.equal(s[:Cout], ref.sum(dim=(0, 2, 3)))
-    assert torch.equal(s[cpad:cpad + Cout], (ref * ref).sum(dim=(0, 2, 3)))
+    s = slab.double().sum(0).cpu()
+    s1, s2 = ref.double().sum(dim=(0, 2, 3)), (ref.double() ** 2).sum(dim=(0, 2, 3))
+    if float(s2.max()) < 2 ** 24:                    # every fp32 partial sum is an exactly representable integer
+        assert torch.equal(s[:Cout], s1) and torch.equal(s[cpad:cpad + Cout], s2)
+    else:                                            # beyond 2^24 the per-tile fp32 partials round: 1e-6 relative
+        assert torch.allclose(s[:Cout], s1, rtol=1e-6, atol=1.0) and torch.allclose(s[cpad:cpad + Cout], s2, rtol=1e-6)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (3, 64, 128, 24, 40),
-                                   (2, 136, 256, 16, 16)])
+                                   (2, 136, 256, 16, 16), (1, 3, 5, 2, 3), (4, 8, 8, 3, 3), (9, 1, 1, 1, 1), (2, 17, 70, 5, 40)])
 def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
     from mau_amd import functional as F_
     from mau_amd._lib import call, lib
