@@ -48,8 +48,8 @@ class ConvTimer:
 
         def call(name, *args):
             if self.enabled and name == "mau_conv3x3_fwd":
-                # args: x, ldx, C0, emb, emb_ws, E, wpk, bias, y, ldy, Cout, slab, dtype, N, H, W, stream
-                C0, E, Cout, N, H, W = args[2], args[5], args[10], args[13], args[14], args[15]
+                # args: x, ldx, C0, emb, emb_ws, E, wpk, bias, post_scale, post_shift, y, ldy, Cout, slab, dtype, N, H, W, stream
+                C0, E, Cout, N, H, W = args[2], args[5], args[12], args[15], args[16], args[17]
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()

@@ -76,12 +76,15 @@ int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W);
  *   emb_ws  workspace of N*E elements of `dtype` (the embedding in the activation dtype; needed for
  *         MAU_BF16 when E > 0, ignored otherwise);
  *   wpk   forward pack for Cin = C0+E;  bias fp32 (Cout) or NULL;
+ *   post_scale/post_shift  optional fp32 (Cout) pair: y = relu(post_scale*(conv+bias) + post_shift) -- eval-mode
+ *         nn.BatchNorm2d + nn.ReLU (src/model.py:13-16) folded into the epilogue for the inference path
+ *         (app/model_utils.py:102-109, test/evaluate.py:181-186); NULL, NULL = plain convolution;
  *   slab  optional fp32 [num_pixel_tiles][2][Cout64]: per-tile sum / sum of squares of y over the
  *         tile's valid pixels (first half of train-mode nn.BatchNorm2d, src/model.py:13,15).
  * The same entry point computes the data gradient when given dy and the `wd` pack. */
 int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* wpk,
-                    const float* bias, void* y, int ldy, int Cout, float* slab, int dtype, int N, int H,
-                    int W, mau_stream_t stream);
+                    const float* bias, const float* post_scale, const float* post_shift, void* y, int ldy,
+                    int Cout, float* slab, int dtype, int N, int H, int W, mau_stream_t stream);
 /* Weight gradient  dW = x (*) dy  reduced over all pixels, in two steps:
  *   mau_conv3x3_wgrad        -> acc: fp32 split-K partial slabs [nsplit][9][Cout64][Cin64]
  *                               (nsplit = mau_conv3x3_wgrad_splits(...); MAU_F32: one slab, zeroed by the call)

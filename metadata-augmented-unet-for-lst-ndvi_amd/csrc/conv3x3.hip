@@ -214,6 +214,8 @@ __global__ __launch_bounds__(NT) void conv3x3_igemm_kernel(ConvP p) {
   // ---- epilogue: bias, BatchNorm partial statistics, store ----
   const int co = co0 + wn * 32 + i32;
   const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+  const bool post = p.post_scale != nullptr;
+  const float psc = (post && co < p.Cout) ? p.post_scale[co] : 0.f, psh = (post && co < p.Cout) ? p.post_shift[co] : 0.f;
   T* __restrict__ yg = reinterpret_cast<T*>(p.y);
   float s = 0.f, q = 0.f;
 #pragma unroll
@@ -224,7 +226,8 @@ __global__ __launch_bounds__(NT) void conv3x3_igemm_kernel(ConvP p) {
       const int ty = wm * 4 + mt * 2 + (prow >> 4), tx = prow & 15;
       const int gy = ty0 + ty, gx = tx0 + tx;
       const bool valid = gy < p.H && gx < p.W;
-      const float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
+      float v = (mt == 0 ? acc0[r] : acc1[r]) + bv;
+      if (post) v = fmaxf(fmaf(v, psc, psh), 0.f);
       if (valid) {
         s += v;
         q += v * v;
@@ -497,15 +500,16 @@ __global__ void cast_f32_to_bf16_kernel(const float* __restrict__ src, bf16* __r
 }
 
 int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* wpk,
-                    const float* bias, void* y, int ldy, int Cout, float* slab, int dtype, int N, int H,
-                    int W, mau_stream_t stream) {
+                    const float* bias, const float* post_scale, const float* post_shift, void* y, int ldy, int Cout,
+                    float* slab, int dtype, int N, int H, int W, mau_stream_t stream) {
   MAU_REQUIRE(x && wpk && y, "conv3x3_fwd: null pointer");
   MAU_REQUIRE(N > 0 && H > 0 && W > 0 && C0 > 0 && Cout > 0, "conv3x3_fwd: bad shape");
   MAU_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C0 && ldy >= Cout, "conv3x3_fwd: ld must be a multiple of 8 and >= C");
   MAU_REQUIRE(E >= 0 && (E == 0 || (emb && E % 8 == 0 && C0 % 8 == 0)), "conv3x3_fwd: broadcast source needs E%%8==0 and C0%%8==0");
   MAU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wpk % 16) == 0, "conv3x3_fwd: pointers must be 16-byte aligned");
+  MAU_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "conv3x3_fwd: post_scale and post_shift come together");
   ConvP p;
-  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.emb_lp = nullptr; p.E = E; p.w = wpk; p.bias = bias; p.y = y; p.ldy = ldy;
+  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.emb_lp = nullptr; p.E = E; p.w = wpk; p.bias = bias; p.post_scale = post_scale; p.post_shift = post_shift; p.y = y; p.ldy = ldy;
   p.Cout = Cout; p.CoutPad = round_up(Cout, 64); p.slab = slab; p.N = N; p.H = H; p.W = W;
   p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
   p.nChunks = ceil_div(C0 + E, mau_conv3x3_kc(dtype));

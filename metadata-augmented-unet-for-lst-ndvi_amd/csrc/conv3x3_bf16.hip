@@ -254,11 +254,14 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
     __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer stage^1 -> reuse it
     bf16* stg = reinterpret_cast<bf16*>(smem + (stage ^ 1) * STAGE) + wave * (32 * 64);   // wave-private 32 px x 64 ch
     float s[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
-    float bv[2];
+    float bv[2], psc[2], psh[2];
+    const bool post = p.post_scale != nullptr;       // eval-mode BatchNorm + ReLU folded into the epilogue
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int co = cur.co0 + wn * 64 + nt * 32 + i32;
       bv[nt] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+      psc[nt] = (post && co < p.Cout) ? p.post_scale[co] : 0.f;
+      psh[nt] = (post && co < p.Cout) ? p.post_shift[co] : 0.f;
     }
     const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
     // validity of this lane's accumulator rows: tile row rowbase[g] + k lies at (y = rowbase[g]>>4 (+2*mt), x = (rowbase[g]&15) + k)
@@ -275,7 +278,8 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
           const bool ok = yok && k < xlim[g];
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
-            const float v = acc[mt][nt][g * 4 + k] + bv[nt];
+            float v = acc[mt][nt][g * 4 + k] + bv[nt];
+            if (post) v = fmaxf(fmaf(v, psc[nt], psh[nt]), 0.f);
             if (ok) {
               s[nt] += v;
               q2[nt] += v * v;

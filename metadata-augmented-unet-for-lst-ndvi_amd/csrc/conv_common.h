@@ -22,6 +22,8 @@ struct ConvP {
   int E;
   const void* w;
   const float* bias;
+  const float* post_scale;   // optional: out = relu(post_scale[co] * (conv + bias) + post_shift[co])  (eval-mode BN + ReLU)
+  const float* post_shift;
   void* y;
   int ldy, Cout, CoutPad;
   float* slab;

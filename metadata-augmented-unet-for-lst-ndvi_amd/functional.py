@@ -222,7 +222,7 @@ class ConvBNReLU(torch.autograd.Function):
             slab = torch.empty((tiles, 2 * cpad), **f32)
             call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,
                  emb_ws.data_ptr() if E else None, E, wf.data_ptr(),
-                 bias.data_ptr(), y.data_ptr(), ldy, Cout, slab.data_ptr(), code, N, H, W, stream)
+                 bias.data_ptr(), None, None, y.data_ptr(), ldy, Cout, slab.data_ptr(), code, N, H, W, stream)
             sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)          # [sum(y) | sum(y^2)]
             ws = torch.empty(2 * lib.mau_reduce_rows_ws_elems(tiles, Cout), dtype=torch.float64, device=dev)
             call("mau_reduce_rows_f64", slab.data_ptr(), tiles, Cout, 2 * cpad, sums.data_ptr(), ws.data_ptr(), stream)
@@ -237,9 +237,15 @@ class ConvBNReLU(torch.autograd.Function):
         else:
             call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                  st.eps, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cout, stream)
+            if not any(ctx.needs_input_grad):
+                # inference: eval-mode BN + ReLU are a fixed per-channel affine map -> folded into the conv epilogue
+                call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,
+                     emb_ws.data_ptr() if E else None, E, wf.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                     y.data_ptr(), ldy, Cout, None, code, N, H, W, stream)
+                return y
             call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,
                  emb_ws.data_ptr() if E else None, E, wf.data_ptr(),
-                 bias.data_ptr(), y.data_ptr(), ldy, Cout, None, code, N, H, W, stream)
+                 bias.data_ptr(), None, None, y.data_ptr(), ldy, Cout, None, code, N, H, W, stream)
         a = torch.empty_like(y)
         call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), ldy, code,
              npix, Cout, stream)
@@ -302,8 +308,8 @@ class ConvBNReLU(torch.autograd.Function):
             wd = PACK_CACHE.get(weight, code, "d")
             ldd = pad8(Cin)
             dfull = torch.empty((N, H, W, ldd), dtype=y.dtype, device=dev)
-            call("mau_conv3x3_fwd", dy.data_ptr(), ldy, Cout, None, None, 0, wd.data_ptr(), None, dfull.data_ptr(), ldd, Cin,
-                 None, code, N, H, W, stream)
+            call("mau_conv3x3_fwd", dy.data_ptr(), ldy, Cout, None, None, 0, wd.data_ptr(), None, None, None, dfull.data_ptr(),
+                 ldd, Cin, None, code, N, H, W, stream)
             if E:
                 if ctx.needs_input_grad[1]:
                     demb = torch.empty((N, E), **f32)

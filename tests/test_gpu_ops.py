@@ -81,7 +81,7 @@ def test_conv3x3_exact_integers(mau, dt, shape):
     tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W)
     cpad = (Cout + 63) // 64 * 64
     slab = torch.zeros((tiles, 2 * cpad), dtype=torch.float32, device="cuda")
-    call("mau_conv3x3_fwd", a.t.data_ptr(), a.t.shape[-1], Cin, None, None, 0, wf.data_ptr(), dev(b).data_ptr(), y.data_ptr(),
+    call("mau_conv3x3_fwd", a.t.data_ptr(), a.t.shape[-1], Cin, None, None, 0, wf.data_ptr(), dev(b).data_ptr(), None, None, y.data_ptr(),
          y.shape[-1], Cout, slab.data_ptr(), code, N, H, W, torch.cuda.current_stream().cuda_stream)
     got = from_act(mau, F_.Act(y, Cout))
     if dt == torch.float32 or float(ref.abs().max()) < 256:
@@ -116,7 +116,7 @@ def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
     wdv = dev(w.detach())
     wdp = F_.PACK_CACHE.get(wdv, code, "d")
     dx = torch.empty((N, H, W, F_.pad8(Cin)), dtype=dt, device="cuda")
-    call("mau_conv3x3_fwd", dya.t.data_ptr(), dya.t.shape[-1], Cout, None, None, 0, wdp.data_ptr(), None, dx.data_ptr(),
+    call("mau_conv3x3_fwd", dya.t.data_ptr(), dya.t.shape[-1], Cout, None, None, 0, wdp.data_ptr(), None, None, None, dx.data_ptr(),
          dx.shape[-1], Cin, None, code, N, H, W, st)
     got_dx = from_act(mau, F_.Act(dx, Cin))
     ref_dx = x.grad if (dt == torch.float32 or float(x.grad.abs().max()) < 256) else x.grad.bfloat16().float()
