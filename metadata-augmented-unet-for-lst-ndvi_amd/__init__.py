@@ -7,6 +7,7 @@ from . import _lib                      # noqa: F401  (raises if the HIP library
 from .model import (MetadataEncoder, TemporalEncoder, UrbanPredictor, UrbanPredictor_unet,  # noqa: F401
                     UrbanPredictor_unetpp, VGGBlock)
 from .losses import compute_loss_mse   # noqa: F401
+from .inference import GraphedInference  # noqa: F401
 
 __all__ = ["UrbanPredictor", "UrbanPredictor_unet", "UrbanPredictor_unetpp", "VGGBlock", "MetadataEncoder",
-           "TemporalEncoder", "compute_loss_mse"]
+           "TemporalEncoder", "compute_loss_mse", "GraphedInference"]

@@ -187,3 +187,21 @@ def test_production_shape_fp32_vs_oracle(mau, model_type, B):
     out16 = net(x.cuda(), ts.cuda(), md.cuda())
     assert torch.isfinite(out16).all()
     assert rel_l2(out16.detach().cpu(), ref.detach()) < 0.1
+
+
+@pytest.mark.parametrize("model_type", ["unet", "unet++"])
+def test_graphed_inference_matches_eager(mau, model_type):
+    """hipGraph-captured inference (app path) == the eager eval forward, also for new input values."""
+    flags = {} if model_type == "unet++" else dict(temporal_embeddings=True, metadata_embeddings=True)
+    torch.manual_seed(3)
+    net = mau.UrbanPredictor(model_type, 23, 12, 16, 8, 16, 24, 2, base_filters=8, **flags).cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    mk = lambda: (torch.randn(1, 23, 96, 96, generator=g).cuda(), torch.randn(1, 12, generator=g).cuda(), torch.randn(1, 8, generator=g).cuda())
+    a, b = mk(), mk()
+    sess = mau.GraphedInference(net, *a)
+    with torch.no_grad():
+        ref_a, ref_b = net(*a), net(*b)
+    assert torch.equal(sess(*a), ref_a)
+    assert torch.equal(sess(*b), ref_b)
+    with pytest.raises(ValueError):
+        sess(torch.zeros(2, 23, 96, 96, device="cuda"), b[1], b[2])
