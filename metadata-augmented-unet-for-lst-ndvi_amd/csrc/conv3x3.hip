@@ -1,16 +1,15 @@
-// conv3x3.hip -- 3x3 / stride 1 / pad 1 convolution on NHWC-ld activations as an im2col-free
-// implicit GEMM on the gfx950 matrix cores.
+// conv3x3.hip -- fp32 PARITY-MODE kernels of the 3x3 / stride 1 / pad 1 convolution on NHWC-ld activations,
+// weight packing / gradient unpacking, and the C entry points that dispatch on dtype
+// (the bf16 throughput kernels live in conv3x3_bf16.hip and conv3x3_wgrad_bf16.hip).
 //
-//   forward / data-gradient :  M = pixels (8x16 spatial tile per workgroup), N = 64 output
-//                              channels, K = 9 taps x KC input channels per chunk.
+// The parity kernels are im2col-free implicit GEMMs on v_mfma_f32_32x32x2_f32, whose result is
+// bit-for-bit a k-ordered fp32 FMA chain (no reduced-precision step anywhere):
+//   forward / data-gradient :  M = pixels (8x16 spatial tile per workgroup), N = 64 output channels,
+//                              K = 9 taps x 16 input channels per chunk; the (8+2)x(16+2) halo tile is
+//                              staged ONCE per chunk in LDS and re-read for the 9 taps at shifted rows.
 //   weight-gradient         :  M = 64 output channels, N = 64 input channels (x 9 taps kept in
-//                              accumulators), K = pixels.
-//
-// One template serves both arithmetic types:
-//   float : v_mfma_f32_32x32x2_f32   (exact fp32 FMA chain -- the parity mode)
-//   bf16  : v_mfma_f32_32x32x16_bf16 (fp32 accumulation   -- the throughput mode)
-// The input halo tile ((8+2)x(16+2) pixels x KC channels) is staged ONCE per channel chunk in LDS
-// and re-read for the 9 taps at shifted pixel offsets; nothing is ever expanded to im2col form.
+//                              accumulators), K = pixels; fp32 atomics into one slab.
+// The templates are written on the element type T but only instantiated for float.
 //
 // Replaces nn.Conv2d(cin, cout, 3, padding=1) of VGGBlock (reference src/model.py:12,14), the
 // first half of train-mode BatchNorm2d (:13,15: per-channel sum / sum of squares, fused into the
@@ -37,15 +36,6 @@ struct Cfg<float> {
   static constexpr int WP = 64;    // wgrad LDS row (elements)
   using frag = float;
 };
-template <>
-struct Cfg<bf16> {
-  static constexpr int KC = 32;
-  static constexpr int KPL = 8;
-  static constexpr int KCP = 40;   // 80-byte rows: 16 consecutive pixels hit 16 distinct 16-B slots
-  static constexpr int VEC = 8;
-  static constexpr int WP = 72;    // 144-byte rows for the transposed reads
-  using frag = bf16x8;
-};
 
 
 template <typename T>
@@ -56,10 +46,6 @@ __device__ __forceinline__ typename Cfg<T>::frag lds_frag(const T* p) {
 // 16 bytes of T moved global -> register -> LDS
 template <typename T>
 __device__ __forceinline__ void lds_put(T* dst, const uint4& v);
-template <>
-__device__ __forceinline__ void lds_put<bf16>(bf16* dst, const uint4& v) {
-  *reinterpret_cast<uint4*>(dst) = v;   // 16-byte aligned by construction
-}
 template <>
 __device__ __forceinline__ void lds_put<float>(float* dst, const uint4& v) {
   // rows are padded to 17 floats -> scalar stores
@@ -73,17 +59,6 @@ __device__ __forceinline__ uint4 pack_emb(const float* e);
 template <>
 __device__ __forceinline__ uint4 pack_emb<float>(const float* e) {
   return *reinterpret_cast<const uint4*>(e);
-}
-template <>
-__device__ __forceinline__ uint4 pack_emb<bf16>(const float* e) {
-  const f32x4 lo = *reinterpret_cast<const f32x4*>(e), hi = *reinterpret_cast<const f32x4*>(e + 4);
-  bf16x8 t;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    t[i] = (bf16)lo[i];
-    t[4 + i] = (bf16)hi[i];
-  }
-  return __builtin_bit_cast(uint4, t);
 }
 
 template <typename T>
@@ -264,22 +239,6 @@ struct WFrag<float> {
     return img[(pix0 + (lane >> 5)) * Cfg<float>::WP + col0 + (lane & 31)];
   }
   static constexpr int KSTEP = 2;
-};
-template <>
-struct WFrag<bf16> {
-  // 32x32x16 operand from a [pixel][channel] LDS image with two transposed 64-bit reads:
-  // lane (r = l&31, h = l>>5) needs channel r at pixels pix0 + 8h + 0..7.
-  static __device__ __forceinline__ bf16x8 load(const bf16* img, int pix0, int col0, int lane) {
-    const int q = (lane & 15) >> 2, pp = lane & 3, g = (lane >> 4) & 1, h = lane >> 5;
-    const bf16* a = img + (pix0 + 8 * h + q) * Cfg<bf16>::WP + col0 + 16 * g + 4 * pp;
-    typedef __attribute__((address_space(3))) s16x4* lptr;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 4 * Cfg<bf16>::WP));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, both);
-  }
-  static constexpr int KSTEP = 16;
 };
 
 template <typename T>

@@ -59,7 +59,12 @@ struct Item {
   int pixTile, n, ty0, tx0, co0;
 };
 
-template <int BN>
+// Epilogue flavours (compile-time, so the training kernels carry no inference code and vice versa)
+constexpr int EPI_PLAIN = 0;   // y = conv (+bias)                      : data gradient
+constexpr int EPI_STATS = 1;   // + BatchNorm partial sums              : training forward
+constexpr int EPI_POST = 2;    // y = relu(scale*(conv+bias) + shift)   : inference (eval-mode BN + ReLU folded in)
+
+template <int BN, int EPI>
 __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
   constexpr int NW = BN / 16;                         // waves per workgroup
   constexpr int W_Q = 9 * BN * 2 / 64;                // wave-DMAs for the weight slab
@@ -254,37 +259,56 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
     __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer stage^1 -> reuse it
     bf16* stg = reinterpret_cast<bf16*>(smem + (stage ^ 1) * STAGE) + wave * (32 * 64);   // wave-private 32 px x 64 ch
     float s[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
-    float bv[2], psc[2], psh[2];
-    const bool post = p.post_scale != nullptr;       // eval-mode BatchNorm + ReLU folded into the epilogue
+    float bv[2], psc[2] = {0.f, 0.f}, psh[2] = {0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int co = cur.co0 + wn * 64 + nt * 32 + i32;
       bv[nt] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
-      psc[nt] = (post && co < p.Cout) ? p.post_scale[co] : 0.f;
-      psh[nt] = (post && co < p.Cout) ? p.post_shift[co] : 0.f;
+      if (EPI == EPI_POST) {
+        psc[nt] = co < p.Cout ? p.post_scale[co] : 0.f;
+        psh[nt] = co < p.Cout ? p.post_shift[co] : 0.f;
+      }
     }
     const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
-    // validity of this lane's accumulator rows: tile row rowbase[g] + k lies at (y = rowbase[g]>>4 (+2*mt), x = (rowbase[g]&15) + k)
+    // interior tiles (the common case) take the mask-free path; the branch is workgroup-uniform
+    const bool full = cur.ty0 + TS <= p.H && cur.tx0 + TS <= p.W;
     int xlim[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) xlim[g] = p.W - cur.tx0 - (rowbase[g] & 15);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+      if (full) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const bool yok = cur.ty0 + wm * 4 + mt * 2 + (rowbase[g] >> 4) < p.H;
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bool ok = yok && k < xlim[g];
+          for (int k = 0; k < 4; ++k)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            float v = acc[mt][nt][g * 4 + k] + bv[nt];
-            if (post) v = fmaxf(fmaf(v, psc[nt], psh[nt]), 0.f);
-            if (ok) {
-              s[nt] += v;
-              q2[nt] += v * v;
+            for (int nt = 0; nt < 2; ++nt) {
+              float v = acc[mt][nt][g * 4 + k] + bv[nt];
+              if (EPI == EPI_POST) v = fmaxf(fmaf(v, psc[nt], psh[nt]), 0.f);
+              if (EPI == EPI_STATS) {
+                s[nt] += v;
+                q2[nt] = fmaf(v, v, q2[nt]);
+              }
+              stg[(rowbase[g] + k) * 64 + nt * 32 + i32] = (bf16)v;
             }
-            stg[(rowbase[g] + k) * 64 + nt * 32 + i32] = (bf16)v;
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bool yok = cur.ty0 + wm * 4 + mt * 2 + (rowbase[g] >> 4) < p.H;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool ok = yok && k < xlim[g];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              float v = acc[mt][nt][g * 4 + k] + bv[nt];
+              if (EPI == EPI_POST) v = fmaxf(fmaf(v, psc[nt], psh[nt]), 0.f);
+              if (EPI == EPI_STATS && ok) {
+                s[nt] += v;
+                q2[nt] = fmaf(v, v, q2[nt]);
+              }
+              stg[(rowbase[g] + k) * 64 + nt * 32 + i32] = (bf16)v;
+            }
           }
         }
       }
@@ -296,14 +320,14 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
           const int prow = pass * 8 + (lane >> 3);
           const int pw = mt * 32 + prow;
           const int gy = cur.ty0 + wm * 4 + (pw >> 4), gx = cur.tx0 + (pw & 15);
-          if (gy < p.H && gx < p.W) {
+          if (full || (gy < p.H && gx < p.W)) {
             const uint4 v = *reinterpret_cast<const uint4*>(stg + prow * 64 + (lane & 7) * 8);
             *reinterpret_cast<uint4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv) = v;
           }
         }
       }
     }
-    if (p.slab != nullptr) {
+    if (EPI == EPI_STATS) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         s[nt] += __shfl_xor(s[nt], 32);
@@ -313,8 +337,7 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
           red[(wm * 2 + 1) * BN + wn * 64 + nt * 32 + i32] = q2[nt];
         }
       }
-      __syncthreads();                                 // (no DMA of this wave can be pending past the K loop's waits
-                                                       //  except the next item's first stage: draining it here is harmless)
+      __syncthreads();                                 // (may also drain the next item's first DMA: harmless)
       if (tid < 2 * BN) {
         const int which = tid / BN, c = tid % BN;
         const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c] + red[(2 * 2 + which) * BN + c] +
@@ -328,7 +351,7 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
   }
 }
 
-template <int BN>
+template <int BN, int EPI>
 static int launch(const ConvP& p, hipStream_t st) {
   constexpr int W_Q = 9 * BN * 2 / 64;
   constexpr int STAGE = HALO_BYTES + W_Q * 1024;
@@ -336,7 +359,7 @@ static int launch(const ConvP& p, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int tilesX = ceil_div(p.W, TS), tilesY = ceil_div(p.H, TS);
@@ -351,16 +374,27 @@ static int launch(const ConvP& p, hipStream_t st) {
   static const int per_cu = getenv("MAU_CONV_WG_PER_CU") ? atoi(getenv("MAU_CONV_WG_PER_CU")) : (BN == 64 ? 2 : 1);
   int grid = 256 * per_cu;
   if (grid > nItems) grid = nItems;                    // nItems is a multiple of 8, and so is 256*per_cu
-  hipLaunchKernelGGL(conv3x3_bf16_kernel<BN>, dim3(grid), dim3(BN * 4), lds, st, q, nPixTiles, nCt, nItems);
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<BN, EPI>), dim3(grid), dim3(BN * 4), lds, st, q, nPixTiles, nCt, nItems);
   return check_launch("conv3x3_bf16_kernel");
 }
 }  // namespace v2
 
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W) { return N * ceil_div(H, v2::TS) * ceil_div(W, v2::TS); }
 
+template <int BN>
+static int launch_bn(const ConvP& p, hipStream_t st) {
+  if (p.post_scale != nullptr) return v2::launch<BN, v2::EPI_POST>(p, st);      // (a post-affine launch carries no slab)
+  if (p.slab != nullptr) return v2::launch<BN, v2::EPI_STATS>(p, st);
+  return v2::launch<BN, v2::EPI_PLAIN>(p, st);
+}
+
 int launch_conv_bf16_v2(const ConvP& p, hipStream_t st) {
-  if (p.CoutPad % 128 == 0) return v2::launch<128>(p, st);
-  return v2::launch<64>(p, st);
+  if (p.post_scale != nullptr && p.slab != nullptr) {
+    set_error("conv3x3_fwd: post_scale/post_shift and the statistics slab are mutually exclusive");
+    return MAU_ERR_ARG;
+  }
+  if (p.CoutPad % 128 == 0) return launch_bn<128>(p, st);
+  return launch_bn<64>(p, st);
 }
 
 }  // namespace mau
