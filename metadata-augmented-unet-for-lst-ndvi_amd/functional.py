@@ -171,6 +171,7 @@ class BNState:
     eps: float = BN_EPS
     group: object = None                  # torch.distributed process group for SyncBN (None = local BN)
     world: int = 1
+    grad_enabled: bool = True             # torch.is_grad_enabled() at call time (invisible inside Function.forward)
 
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
@@ -237,7 +238,7 @@ class ConvBNReLU(torch.autograd.Function):
         else:
             call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                  st.eps, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cout, stream)
-            if not any(ctx.needs_input_grad):
+            if not st.grad_enabled or not any(ctx.needs_input_grad):
                 # inference: eval-mode BN + ReLU are a fixed per-channel affine map -> folded into the conv epilogue
                 call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,
                      emb_ws.data_ptr() if E else None, E, wf.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),

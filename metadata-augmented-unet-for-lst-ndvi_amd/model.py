@@ -69,7 +69,7 @@ class VGGBlock(nn.Module):
     def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d) -> Act:
         rt = self._rt or _Runtime()
         st = BNState(training=self.training and bn.training, C0=x.C, momentum=bn.momentum, eps=bn.eps,
-                     group=rt.group, world=rt.world)
+                     group=rt.group, world=rt.world, grad_enabled=torch.is_grad_enabled())
         t = F_.ConvBNReLU.apply(x.t, emb, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                 bn.running_var, bn.num_batches_tracked, st)
         return Act(t, conv.out_channels)
