@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must load ITS HIP runtime (libamdhip64) first: libmau_hip.so then binds to that same runtime
+# instance by SONAME.  Loading libmau_hip.so first would bring in a second runtime instance that owns
+# no device ("no ROCm-capable device is detected" on the first launch).
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmau_hip.so")
 

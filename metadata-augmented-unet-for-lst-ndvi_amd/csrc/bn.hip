@@ -47,10 +47,10 @@ template <typename OutT>
 static int reduce_rows_launch(const float* slab, int rows, int M, int ldrow, OutT* out, double* ws, hipStream_t st) {
   const int chunks = reduce_chunks(rows);
   if (chunks == 1 || ws == nullptr) {
-    hipLaunchKernelGGL((reduce_rows_kernel<float, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, slab, rows, M, ldrow, out, M);
+    MAU_LAUNCH((reduce_rows_kernel<float, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, slab, rows, M, ldrow, out, M);
   } else {
-    hipLaunchKernelGGL((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, ldrow, ws, M);
-    hipLaunchKernelGGL((reduce_rows_kernel<double, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, (const double*)ws, chunks, M, M, out, M);
+    MAU_LAUNCH((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, ldrow, ws, M);
+    MAU_LAUNCH((reduce_rows_kernel<double, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, (const double*)ws, chunks, M, M, out, M);
   }
   return check_launch("reduce_rows_kernel");
 }
@@ -309,7 +309,7 @@ int mau_bn_finalize_train(const double* sums, double count, const float* gamma, 
                           float* scale, float* shift, float* mean, float* invstd, int C, mau_stream_t stream) {
   MAU_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0, "bn_finalize_train: bad arguments");
   MAU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_train: running_mean/var must come together");
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
+  MAU_LAUNCH(bn_finalize_train_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
                      beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd, C);
   return check_launch("bn_finalize_train_kernel");
 }
@@ -317,7 +317,7 @@ int mau_bn_finalize_train(const double* sums, double count, const float* gamma, 
 int mau_bn_coeffs_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, float* mean, float* invstd, int C, mau_stream_t stream) {
   MAU_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_coeffs_eval: bad arguments");
-  hipLaunchKernelGGL(bn_coeffs_eval_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+  MAU_LAUNCH(bn_coeffs_eval_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
                      running_mean, running_var, eps, scale, shift, mean, invstd, C);
   return check_launch("bn_coeffs_eval_kernel");
 }
@@ -328,7 +328,7 @@ int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* s
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && lda % 8 == 0 && ldy >= C8 && lda >= C8, "bn_relu_apply: bad ld");
   const int pixb = pixvec_pixels_per_block(C8 / 8);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bn_relu_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)y, ldy, scale, shift, (T*)a, lda, npix, C, C8, pixb));
   return check_launch("bn_relu_apply_kernel");
 }
@@ -341,7 +341,7 @@ int mau_bn_relu_bwd_reduce(const void* da, int ldda, const void* y, int ldy, con
   MAU_REQUIRE(da && y && scale && shift && mean && invstd && slab && npix > 0 && C > 0, "bn_relu_bwd_reduce: bad arguments");
   MAU_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && ldslab >= C, "bn_relu_bwd_reduce: bad ld");
   dim3 grid(mau_bn_bwd_rows(npix), ceil_div(C, 64));
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bn_relu_bwd_reduce_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
                                                (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, slab,
                                                ldslab, npix, C));
   return check_launch("bn_relu_bwd_reduce_kernel");
@@ -354,7 +354,7 @@ int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, cons
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && lddy >= C8, "bn_relu_bwd_apply: bad ld");
   const int pixb = pixvec_pixels_per_block(C8 / 8);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bn_relu_bwd_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, sums,
                                                1.0 / count, (T*)dy, lddy, npix, C, C8, pixb));
   return check_launch("bn_relu_bwd_apply_kernel");

@@ -404,7 +404,7 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(p.N * p.tilesX * p.tilesY, p.CoutPad / BN);
-  hipLaunchKernelGGL(conv3x3_igemm_kernel<T>, grid, dim3(NT), lds, st, p);
+  MAU_LAUNCH(conv3x3_igemm_kernel<T>, grid, dim3(NT), lds, st, p);
   return check_launch("conv3x3_igemm_kernel");
 }
 
@@ -422,7 +422,7 @@ static int launch_wgrad(const WgradP& p, hipStream_t st) {
   if (splits > p.nTiles) splits = p.nTiles;
   if (splits < 1) splits = 1;
   dim3 grid(splits, p.CoutPad / 64, p.CinPad / 64);
-  hipLaunchKernelGGL(conv3x3_wgrad_kernel<T>, grid, dim3(NT), lds, st, p);
+  MAU_LAUNCH(conv3x3_wgrad_kernel<T>, grid, dim3(NT), lds, st, p);
   return check_launch("conv3x3_wgrad_kernel");
 }
 
@@ -445,7 +445,7 @@ int mau_conv3x3_pack_weights(const float* w, void* wf, void* wd, int dtype, int 
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (wf ? mau_conv3x3_packed_elems(dtype, Cout, Cin) : 0) + (wd ? mau_conv3x3_packed_elems(dtype, Cin, Cout) : 0);
   const int grid = stream_grid((int64_t)total, 256);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(grid), dim3(256), 0, st, w, (T*)wf, (T*)wd, Cout, Cin));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(pack_weights_kernel<T>, dim3(grid), dim3(256), 0, st, w, (T*)wf, (T*)wd, Cout, Cin));
   return check_launch("pack_weights_kernel");
 }
 
@@ -477,7 +477,7 @@ int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_
   if (dtype == MAU_BF16) {
     if (E > 0) {
       MAU_REQUIRE(emb_ws != nullptr && ((uintptr_t)emb_ws % 16) == 0, "conv3x3_fwd: bf16 broadcast source needs the (N,E) bf16 workspace emb_ws");
-      hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
+      MAU_LAUNCH(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
       p.emb_lp = emb_ws;
     }
     return launch_conv_bf16_v2(p, st);
@@ -509,7 +509,7 @@ int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* em
   if (dtype == MAU_BF16) {
     if (E > 0) {
       MAU_REQUIRE(emb_ws != nullptr && ((uintptr_t)emb_ws % 16) == 0, "conv3x3_wgrad: bf16 broadcast source needs the (N,E) bf16 workspace emb_ws");
-      hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
+      MAU_LAUNCH(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
       p.emb_lp = emb_ws;
     }
     return launch_wgrad_bf16_v2(p, st);        // split-K partial slabs, plain stores (no memset needed)
@@ -525,7 +525,7 @@ int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* em
 int mau_conv3x3_unpack_wgrad(const float* acc, int nsplit, float* dw, int Cout, int Cin, mau_stream_t stream) {
   MAU_REQUIRE(acc && dw && Cout > 0 && Cin > 0 && nsplit >= 1, "unpack_wgrad: bad arguments");
   const int grid = stream_grid((int64_t)Cout * Cin, 256);
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, nsplit, dw, Cout, Cin,
+  MAU_LAUNCH(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, nsplit, dw, Cout, Cin,
                      round_up(Cout, 64), round_up(Cin, 64));
   return check_launch("unpack_wgrad_kernel");
 }

@@ -374,7 +374,7 @@ static int launch(const ConvP& p, hipStream_t st) {
   static const int per_cu = getenv("MAU_CONV_WG_PER_CU") ? atoi(getenv("MAU_CONV_WG_PER_CU")) : (BN == 64 ? 2 : 1);
   int grid = 256 * per_cu;
   if (grid > nItems) grid = nItems;                    // nItems is a multiple of 8, and so is 256*per_cu
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<BN, EPI>), dim3(grid), dim3(BN * 4), lds, st, q, nPixTiles, nCt, nItems);
+  MAU_LAUNCH((conv3x3_bf16_kernel<BN, EPI>), dim3(grid), dim3(BN * 4), lds, st, q, nPixTiles, nCt, nItems);
   return check_launch("conv3x3_bf16_kernel");
 }
 }  // namespace v2

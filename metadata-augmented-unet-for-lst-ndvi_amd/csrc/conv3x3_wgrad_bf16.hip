@@ -190,7 +190,7 @@ static int launch(const WgradP& p, int nsplit, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(nsplit, p.CoutPad / BCO, p.CinPad / BCI);
-  hipLaunchKernelGGL(wgrad_bf16_kernel<BCO>, grid, dim3(BCO * 4), lds, st, p, nsplit);
+  MAU_LAUNCH(wgrad_bf16_kernel<BCO>, grid, dim3(BCO * 4), lds, st, p, nsplit);
   return check_launch("wgrad_bf16_kernel");
 }
 }  // namespace wg2

@@ -248,7 +248,7 @@ int mau_head_fwd(const void* a, int lda, const float* w, const float* b, float* 
   const int grid = stream_grid(npix, 256);
   const size_t lds = (size_t)Co * round_up(C, 8) * sizeof(float);
   MAU_REQUIRE(lds <= 48 * 1024, "head_fwd: C too large");
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(head_fwd_kernel<T>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const T*)a, lda, w, b, out, tanh0, HW, C, Co, npix));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(head_fwd_kernel<T>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const T*)a, lda, w, b, out, tanh0, HW, C, Co, npix));
   return check_launch("head_fwd_kernel");
 }
 
@@ -263,7 +263,7 @@ int mau_head_bwd(const void* a, int lda, const float* w, const float* out, const
   MAU_REQUIRE(lda % 8 == 0 && ldda % 8 == 0 && lda >= C8 && ldda >= C8, "head_bwd: bad ld");
   const int64_t npix = (int64_t)N * HW;
   const size_t lds = (size_t)32 * HEAD_MAX_CO * 65 * sizeof(float);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(head_bwd_kernel<T>, dim3(mau_head_bwd_rows(N, HW)), dim3(256), lds, (hipStream_t)stream, (const T*)a, lda, w, out, dout, (T*)da, ldda, slab, tanh0, HW, C, C8, Co, npix));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(head_bwd_kernel<T>, dim3(mau_head_bwd_rows(N, HW)), dim3(256), lds, (hipStream_t)stream, (const T*)a, lda, w, out, dout, (T*)da, ldda, slab, tanh0, HW, C, C8, Co, npix));
   return check_launch("head_bwd_kernel");
 }
 
@@ -271,15 +271,15 @@ int mau_meta_mlp_fwd(const float* md, const float* w0, const float* b0, const fl
                      float* emb, int N, int F, int Hd, int D, mau_stream_t stream) {
   MAU_REQUIRE(md && w0 && b0 && w2 && b2 && hidden && emb && N > 0 && F > 0 && Hd > 0 && D > 0, "meta_mlp_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(meta_mlp_fwd_kernel, dim3(ceil_div(N * Hd, 256)), dim3(256), 0, st, md, w0, b0, w2, b2, hidden, emb, N, F, Hd, D);
-  hipLaunchKernelGGL(meta_mlp_fwd2_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, st, hidden, w2, b2, emb, N, Hd, D);
+  MAU_LAUNCH(meta_mlp_fwd_kernel, dim3(ceil_div(N * Hd, 256)), dim3(256), 0, st, md, w0, b0, w2, b2, hidden, emb, N, F, Hd, D);
+  MAU_LAUNCH(meta_mlp_fwd2_kernel, dim3(ceil_div(N * D, 256)), dim3(256), 0, st, hidden, w2, b2, emb, N, Hd, D);
   return check_launch("meta_mlp_fwd_kernel");
 }
 
 int mau_meta_mlp_bwd(const float* md, const float* w0, const float* w2, const float* hidden, const float* demb, float* dw0,
                      float* db0, float* dw2, float* db2, float* dhidden_ws, int N, int F, int Hd, int D, mau_stream_t stream) {
   MAU_REQUIRE(md && w0 && w2 && hidden && demb && dw0 && db0 && dw2 && db2 && dhidden_ws, "meta_mlp_bwd: null pointer");
-  hipLaunchKernelGGL(meta_mlp_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, md, w0, w2, hidden, demb, dw0, db0, dw2, db2, dhidden_ws, N, F, Hd, D);
+  MAU_LAUNCH(meta_mlp_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, md, w0, w2, hidden, demb, dw0, db0, dw2, db2, dhidden_ws, N, F, Hd, D);
   return check_launch("meta_mlp_bwd_kernel");
 }
 
@@ -291,8 +291,8 @@ int mau_mse_fwd_bwd(const float* out, const float* tgt, double* partial, float* 
   MAU_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)tgt % 16) == 0 && (!dout || ((uintptr_t)dout % 16) == 0), "mse_fwd_bwd: 16-byte alignment required");
   hipStream_t st = (hipStream_t)stream;
   const int blocks = mau_mse_blocks(n);
-  hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, st, out, tgt, partial, dout, n, 2.0f / (float)n);
-  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks, 1.0 / (double)n, loss);
+  MAU_LAUNCH(mse_kernel, dim3(blocks), dim3(256), 0, st, out, tgt, partial, dout, n, 2.0f / (float)n);
+  MAU_LAUNCH(mse_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks, 1.0 / (double)n, loss);
   return check_launch("mse_kernel");
 }
 

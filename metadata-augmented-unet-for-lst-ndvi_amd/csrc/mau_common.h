@@ -17,6 +17,14 @@ namespace mau {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Launch with a clean error slate: hipGetLastError() is sticky per thread and would otherwise report a
+// benign earlier error of some other component in the process as this launch's failure.
+#define MAU_LAUNCH(...)               \
+  do {                                \
+    (void)hipGetLastError();          \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+  } while (0)
+
 #define MAU_REQUIRE(cond, ...)                      \
   do {                                              \
     if (!(cond)) {                                  \

@@ -261,7 +261,7 @@ int mau_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H
   MAU_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld % 8 == 0 && ld >= C, "nchw_to_nhwc: bad arguments");
   const int64_t HW = (int64_t)H * W;
   dim3 grid(ceil_div(HW, 256), ceil_div(round_up(C, 8), 8), N);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst, C, HW, ld));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(nchw_to_nhwc_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst, C, HW, ld));
   return check_launch("nchw_to_nhwc_kernel");
 }
 
@@ -269,7 +269,7 @@ int mau_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H
   MAU_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld % 8 == 0 && ld >= C, "nhwc_to_nchw: bad arguments");
   const int64_t HW = (int64_t)H * W;
   dim3 grid(ceil_div(HW, 256), ceil_div(C, 8), N);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, dst, C, HW, ld));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, dst, C, HW, ld));
   return check_launch("nhwc_to_nchw_kernel");
 }
 
@@ -278,7 +278,7 @@ int mau_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int 
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C8 && ldy >= C8, "maxpool2x2_fwd: bad ld");
   const int grid = stream_grid((int64_t)N * (H / 2) * (W / 2) * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, N, H, W, C8));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(maxpool_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, N, H, W, C8));
   return check_launch("maxpool_fwd_kernel");
 }
 
@@ -288,7 +288,7 @@ int mau_maxpool2x2_bwd(const void* x, int ldx, const void* dy, int lddy, void* d
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldx >= C8 && lddy >= C8 && lddx >= C8, "maxpool2x2_bwd: bad ld");
   const int grid = stream_grid((int64_t)N * H * W * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C8));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(maxpool_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C8));
   return check_launch("maxpool_bwd_kernel");
 }
 
@@ -298,7 +298,7 @@ int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst,
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldsrc % 8 == 0 && lddst % 8 == 0 && choff % 8 == 0 && ldsrc >= C8 && lddst >= choff + C8, "resize_bilinear_fwd: bad ld/choff");
   const int grid = stream_grid((int64_t)N * H * W * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(resize_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, N, H, W, C8));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, N, H, W, C8));
   return check_launch("resize_fwd_kernel");
 }
 
@@ -308,7 +308,7 @@ int mau_resize_bilinear_bwd(const void* ddst, int ldddst, int choff, int H, int 
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldddst % 8 == 0 && lddsrc % 8 == 0 && choff % 8 == 0 && lddsrc >= C8 && ldddst >= choff + C8, "resize_bilinear_bwd: bad ld/choff");
   const int grid = stream_grid((int64_t)N * h * w * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(resize_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)ddst, ldddst, choff, H, W, (T*)dsrc, lddsrc, N, h, w, C8));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)ddst, ldddst, choff, H, W, (T*)dsrc, lddsrc, N, h, w, C8));
   return check_launch("resize_bwd_kernel");
 }
 
@@ -319,11 +319,11 @@ int mau_copy_channels(const void* src, int ldsrc, void* dst, int lddst, int chof
   const bool vec = (C % 8 == 0) && (choff % 8 == 0) && (ldsrc % 8 == 0) && (lddst % 8 == 0) && zero_to <= choff + C;
   if (vec) {
     const int grid = stream_grid(npix * (C / 8), 256);
-    MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(copy_channels_vec_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)src, ldsrc, (T*)dst, lddst, choff, npix, C));
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(copy_channels_vec_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)src, ldsrc, (T*)dst, lddst, choff, npix, C));
   } else {
     const int span = (zero_to > choff + C ? zero_to : choff + C) - choff;
     const int grid = stream_grid(npix * span, 256);
-    MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(copy_channels_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)src, ldsrc, (T*)dst, lddst, choff, zero_to, npix, C));
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(copy_channels_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)src, ldsrc, (T*)dst, lddst, choff, zero_to, npix, C));
   }
   return check_launch("copy_channels_kernel");
 }
@@ -334,14 +334,14 @@ int mau_bcast_fill(const float* emb, void* dst, int lddst, int choff, int zero_t
   const int span = (zero_to > choff + E ? zero_to : choff + E) - choff;
   const int64_t npix = (int64_t)N * HW;
   const int grid = stream_grid(npix * span, 256);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bcast_fill_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, emb, (T*)dst, lddst, choff, zero_to, HW, E, npix));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bcast_fill_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, emb, (T*)dst, lddst, choff, zero_to, HW, E, npix));
   return check_launch("bcast_fill_kernel");
 }
 
 int mau_bcast_bwd(const void* dx, int lddx, int choff, float* demb, int dtype, int N, int HW, int E, mau_stream_t stream) {
   MAU_REQUIRE(dx && demb && N > 0 && HW > 0 && E > 0 && lddx >= choff + E, "bcast_bwd: bad arguments");
   dim3 grid(ceil_div(E, 64), N);
-  MAU_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bcast_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)dx, lddx, choff, demb, HW, E));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bcast_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)dx, lddx, choff, demb, HW, E));
   return check_launch("bcast_bwd_kernel");
 }
 

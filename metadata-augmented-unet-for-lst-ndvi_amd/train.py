@@ -1,0 +1,116 @@
+"""Training driver with the reference's CLI surface (src/train.py:62-73) around the HIP hot path.
+
+    python -m mau_amd.train --device gpu --model-type unet --no-temporal-embeddings --epochs 1 --steps-per-epoch 20
+
+The reference wraps the step in Optuna trials, wandb logging and a dataset that is not shipped
+(SURVEY D9); none of that is on the hot path.  This driver keeps: the flags, the study-name suffix
+rule (:79-87), seeding (:104), model construction (:194-207), optimizer / loss selection
+(:209-225), the inner step (:243-256), best-loss checkpointing in the exact ``.pth`` layout
+(:303-319) -- on synthetic batches with the loader's tuple layout (src/dataset.py:87-108).
+Single process, or data parallel under ``torch.distributed.run`` (RCCL).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import typer
+
+from . import compute_loss_mse
+from .checkpoint import build_hyperparameters, save_checkpoint
+from .config import CONFIG
+from .dist import GradSync, init_process_group_from_env
+from .model import UrbanPredictor
+
+app = typer.Typer(add_completion=False)
+
+
+def synthetic_batch(batch_size: int, device, gen: torch.Generator):
+    """(inputs, metadatas, temp_series_padded, temp_series_lengths, t1_dates, t2_dates, targets), src/dataset.py:87-108."""
+    ds = CONFIG.dataset
+    e = ds.image_shape_edge
+    mk = lambda *s: torch.randn(*s, generator=gen).to(device)
+    n_meta = ds.nb_metadata_features
+    return (mk(batch_size, ds.nb_input_channels, e, e), mk(batch_size, n_meta - 4 if n_meta >= 8 else n_meta),
+            mk(batch_size, 24), torch.full((batch_size,), 24), mk(batch_size, 2), mk(batch_size, 2),
+            mk(batch_size, len(ds.target_channels), e, e))
+
+
+@app.command()
+def main(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study_name: bool = False,
+         temporal_embeddings: bool = True, metadata_embeddings: bool = True, study_name: str = "urban-predictor",
+         model_type: str = "unet++", jobid: str = "", epochs: Optional[int] = None, steps_per_epoch: int = 20,
+         precision: str = "bf16"):
+    assert model_type in ["unet", "unet++"], "model_type must be 'unet' or 'unet++'"          # src/train.py:78
+    if not force_study_name:                                                                  # src/train.py:79-87
+        study_name += "-emb" if temporal_embeddings and metadata_embeddings else "-tempemb" if temporal_embeddings \
+            else "-metaemb" if metadata_embeddings else "-noemb"
+    if device.lower() == "cpu":
+        raise typer.BadParameter("this is the MI355X-native path: --device gpu (there is no CPU fallback)")
+    rank, local, world = init_process_group_from_env()
+    CONFIG.device = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    torch.manual_seed(CONFIG.seed)                                                            # src/train.py:104
+    cfg = CONFIG.training
+    n_meta = CONFIG.dataset.nb_metadata_features
+    model = UrbanPredictor(model_type=model_type, spatial_channels=CONFIG.dataset.nb_input_channels,
+                           seq_len=CONFIG.dataset.temporal_length, temporal_dim=cfg.temporal_dim, meta_features=n_meta,
+                           meta_dim=cfg.meta_dim, lstm_dim=cfg.lstm_hidden, out_channels=len(CONFIG.dataset.target_channels),
+                           deep_supervision=False, temporal_embeddings=temporal_embeddings,
+                           metadata_embeddings=metadata_embeddings).to(CONFIG.device)              # src/train.py:194-206
+    model.set_precision(precision).train()
+    if cfg.optimizer == "SGD":                                                                # src/train.py:209-216
+        optimizer = torch.optim.SGD(model.parameters(), lr=cfg.learning_rate, momentum=cfg.momentum)
+    elif cfg.optimizer == "Adam":
+        optimizer = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    elif cfg.optimizer == "AdamW":
+        optimizer = torch.optim.AdamW(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    else:
+        raise NotImplementedError(f"Optimizer {cfg.optimizer} not implemented.")
+    if cfg.loss == "mse":                                                                     # src/train.py:218-225
+        criterion = compute_loss_mse
+    else:
+        raise NotImplementedError(f"Loss {cfg.loss} not implemented.")
+    sync = None
+    if world > 1:
+        import torch.distributed as dist
+        model.set_sync_bn(dist.group.WORLD)
+        sync = GradSync(model)
+    hyper = build_hyperparameters(cfg, model_type, temporal_embeddings, metadata_embeddings,
+                                  CONFIG.dataset.nb_input_channels, CONFIG.dataset.target_channels)
+    gen = torch.Generator().manual_seed(CONFIG.seed + rank)
+    best, step = float("inf"), 0
+    for epoch in range(epochs if epochs is not None else cfg.epochs):
+        model.train()
+        total = 0.0
+        for _ in range(steps_per_epoch):
+            inputs, metadata, temp_series, _lengths, t1, t2, targets = synthetic_batch(cfg.batch_size, CONFIG.device, gen)
+            metadata_full = torch.cat([metadata, t1, t2], dim=1) if n_meta >= 8 else metadata  # src/train.py:244
+            outputs = model(inputs, temp_series, metadata_full)                             # src/train.py:245
+            batch_loss = criterion(outputs, targets).get("total", None)                     # src/train.py:247-249
+            if sync is not None:
+                sync.begin()
+            batch_loss.backward()
+            if sync is not None:
+                sync.finish()
+            if cfg.gradient_clipping > 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)                     # src/train.py:253-254
+            optimizer.step()
+            optimizer.zero_grad()
+            total += batch_loss.detach().cpu().item()                                       # src/train.py:258
+            step += 1
+        epoch_loss = total / steps_per_epoch
+        if rank == 0:
+            typer.echo(f"epoch {epoch} step {step} train loss {epoch_loss:.6f}")
+            if epoch_loss < best:                                                           # src/train.py:303-319
+                best = epoch_loss
+                name = f"{study_name}_trial_0_best_job{jobid}.pth"
+                save_checkpoint(os.path.join(CONFIG.MODELS_DIR, name), model, optimizer, epoch=epoch, step=step, loss=best,
+                                hyperparameters=hyper, model_type=model_type, study_name=study_name, trial_id=0,
+                                metadata_input_length=n_meta)
+    return best
+
+
+if __name__ == "__main__":
+    app()

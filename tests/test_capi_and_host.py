@@ -126,3 +126,36 @@ def test_precision_switch_and_env(monkeypatch):
         net.set_precision("fp8")
     monkeypatch.setenv("MAU_PRECISION", "fp32")
     assert mau_amd.UrbanPredictor("unet", 6, 10, 8, 4, 8, 12, 2, base_filters=4).model._rt.precision == "fp32"
+
+
+def test_checkpoint_reader_rules_and_roundtrip(tmp_path):
+    """Reader resolution rules of app/model_utils.py:38-74 / test/evaluate.py:85-113 and the writer's dict
+    (src/train.py:305-316); construction + strict load work on CPU (only forward needs the GPU)."""
+    import mau_amd
+    from mau_amd import checkpoint as C
+    from mau_amd.config import CONFIG
+    f = C.resolve_embedding_flags
+    assert f({"hyperparameters": {"temporal_embeddings": False, "metadata_embeddings": True}}) == (False, True)
+    assert f({}) == (True, True)                                                   # legacy default
+    assert f({"study_name": "urban-predictor-noemb"}) == (False, False)
+    assert f({"additional_embeddings": False, "metadata_only_embeddings": True}) == (False, True)
+    assert f({}, study_name="x-noemb") == (False, False)
+    kw = C.model_kwargs_from_checkpoint({})
+    assert (kw["model_type"], kw["meta_features"], kw["temporal_dim"], kw["meta_dim"], kw["lstm_dim"]) == ("unet", 4, 64, 64, 96)
+    assert CONFIG.training.learning_rate == 1e-4 and CONFIG.dataset.nb_input_channels == 23
+    # write with the reference's layout, read back through the loader mirror
+    net = mau_amd.UrbanPredictor("unet", 23, 10, 8, 8, 8, 12, 2, base_filters=64, temporal_embeddings=False, metadata_embeddings=True)
+    hyper = {"temporal_dim": 8, "meta_dim": 8, "lstm_hidden": 12, "temporal_embeddings": False, "metadata_embeddings": True}
+    path = str(tmp_path / "m.pth")
+    ck = C.save_checkpoint(path, net, None, epoch=1, step=2, loss=0.5, hyperparameters=hyper, model_type="unet",
+                           study_name="urban-predictor-metaemb", trial_id=3, metadata_input_length=8)
+    assert list(ck) == ["epoch", "step", "model_state_dict", "optimizer_state_dict", "loss", "hyperparameters", "model_type",
+                        "study_name", "trial_id", "metadata_input_length"]
+    back = C.load_model(path, device="cpu", clean=True)
+    assert not back.training and back.model.temporal_embeddings is False and back.model.metadata_embeddings is True
+    for k, v in net.state_dict().items():
+        assert torch.equal(back.state_dict()[k], v), k
+    assert "optimizer_state_dict" not in torch.load(path, weights_only=False)       # the reference's clean-up side effect
+    # bare state_dict and 'state_dict' variants (app/model_utils.py:91-96)
+    torch.save({"state_dict": net.state_dict(), "hyperparameters": hyper, "metadata_input_length": 8}, path)
+    C.load_model(path, device="cpu")
