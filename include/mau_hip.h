@@ -156,7 +156,10 @@ int mau_copy_channels(const void* src, int ldsrc, void* dst, int lddst, int chof
 int mau_bcast_fill(const float* emb, void* dst, int lddst, int choff, int zero_to, int dtype, int N, int HW,
                    int E, mau_stream_t stream);
 /* demb (N,E) fp32 = sum over pixels of dx[..., choff:choff+E]  (adjoint of the embedding broadcast). */
-int mau_bcast_bwd(const void* dx, int lddx, int choff, float* demb, int dtype, int N, int HW, int E,
+/* ws: fp32 workspace of mau_bcast_bwd_ws_elems(N, HW, E) elements (per-chunk partial sums, summed in
+ * fixed order); NULL selects the slow element-granular path. */
+size_t mau_bcast_bwd_ws_elems(int N, int HW, int E);
+int mau_bcast_bwd(const void* dx, int lddx, int choff, float* demb, float* ws, int dtype, int N, int HW, int E,
                   mau_stream_t stream);
 
 /* ---- head: 1x1 conv + tanh on channel 0 (src/model.py:241,284-292) -------- */

@@ -53,7 +53,8 @@ PROTOTYPES = {
     "mau_resize_bilinear_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_copy_channels": (_i, [_p, _i, _p, _i, _i, _i, _i, _i64, _i, _p]),
     "mau_bcast_fill": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "mau_bcast_bwd": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "mau_bcast_bwd_ws_elems": (_sz, [_i, _i, _i]),
+    "mau_bcast_bwd": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p]),
     "mau_head_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_head_bwd": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_head_bwd_rows": (_i, [_i, _i]),

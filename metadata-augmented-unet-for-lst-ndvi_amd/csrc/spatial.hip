@@ -237,7 +237,60 @@ __global__ __launch_bounds__(256) void bcast_fill_kernel(const float* __restrict
   }
 }
 
-// demb[n][e] = sum over the HW pixels of dx[n, :, choff + e]; block per (n, 64-channel group)
+// demb[n][e] = sum over the HW pixels of dx[n, :, choff + e]  (adjoint of the embedding broadcast).
+// Level 1: workgroup (64-channel group, image n, pixel chunk) -- 8 channel vectors x 32 pixel slots,
+// 16-byte loads, 2 pixels in flight per lane -- writes a partial row [n][chunk][E]; level 2 adds the
+// chunks in fixed order (deterministic, no atomics).  U-Net++ broadcasts the embedding into every
+// decoder node up to 256x256 (src/model.py:136-177), so H*W reaches 65,536 pixels per image.
+constexpr int BCAST_PIX_PER_CHUNK = 2048;
+
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_bwd_partial_kernel(const T* __restrict__ dx, int lddx, int choff,
+                                                                float* __restrict__ part, int HW, int E, int nchunks) {
+  __shared__ float red[32][64 + 1];
+  const int cv = threadIdx.x & 7, ps = threadIdx.x >> 3;
+  const int n = blockIdx.y, chunk = blockIdx.z;
+  const int e0 = blockIdx.x * 64 + cv * 8;
+  const int p0 = chunk * BCAST_PIX_PER_CHUNK, p1 = min(HW, p0 + BCAST_PIX_PER_CHUNK);
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  if (e0 < E) {
+    const T* base = dx + (size_t)n * HW * lddx + choff + e0;
+    int p = p0 + ps;
+    for (; p + 32 < p1; p += 64) {
+      const F8 a = load8<T>(base + (size_t)p * lddx), b = load8<T>(base + (size_t)(p + 32) * lddx);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += a.v[j] + b.v[j];
+    }
+    for (; p < p1; p += 32) {
+      const F8 a = load8<T>(base + (size_t)p * lddx);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += a.v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ps][cv * 8 + j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    float t = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+    if (e < E) part[((size_t)n * nchunks + chunk) * E + e] = t;
+  }
+}
+
+__global__ void bcast_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ demb, int NE, int E, int nchunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NE) return;
+  const int n = i / E, e = i % E;
+  float t = 0.f;
+  for (int c = 0; c < nchunks; ++c) t += part[((size_t)n * nchunks + c) * E + e];
+  demb[i] = t;
+}
+
+// element-granular fallback (channel offset / count not a multiple of 8: tiny test models only)
 template <typename T>
 __global__ __launch_bounds__(256) void bcast_bwd_kernel(const T* __restrict__ dx, int lddx, int choff, float* __restrict__ demb,
                                                         int HW, int E) {
@@ -338,11 +391,23 @@ int mau_bcast_fill(const float* emb, void* dst, int lddst, int choff, int zero_t
   return check_launch("bcast_fill_kernel");
 }
 
-int mau_bcast_bwd(const void* dx, int lddx, int choff, float* demb, int dtype, int N, int HW, int E, mau_stream_t stream) {
+size_t mau_bcast_bwd_ws_elems(int N, int HW, int E) { return (size_t)N * ceil_div(HW, BCAST_PIX_PER_CHUNK) * E; }
+
+int mau_bcast_bwd(const void* dx, int lddx, int choff, float* demb, float* ws, int dtype, int N, int HW, int E,
+                  mau_stream_t stream) {
   MAU_REQUIRE(dx && demb && N > 0 && HW > 0 && E > 0 && lddx >= choff + E, "bcast_bwd: bad arguments");
-  dim3 grid(ceil_div(E, 64), N);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bcast_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)dx, lddx, choff, demb, HW, E));
-  return check_launch("bcast_bwd_kernel");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = ws != nullptr && choff % 8 == 0 && E % 8 == 0 && lddx % 8 == 0 && ((uintptr_t)dx % 16) == 0;
+  if (!vec) {
+    dim3 grid(ceil_div(E, 64), N);
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bcast_bwd_kernel<T>, grid, dim3(256), 0, st, (const T*)dx, lddx, choff, demb, HW, E));
+    return check_launch("bcast_bwd_kernel");
+  }
+  const int nchunks = ceil_div(HW, BCAST_PIX_PER_CHUNK);
+  dim3 grid(ceil_div(E, 64), N, nchunks);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bcast_bwd_partial_kernel<T>, grid, dim3(256), 0, st, (const T*)dx, lddx, choff, ws, HW, E, nchunks));
+  MAU_LAUNCH(bcast_bwd_final_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, ws, demb, N * E, E, nchunks);
+  return check_launch("bcast_bwd_partial_kernel");
 }
 
 }  // extern "C"

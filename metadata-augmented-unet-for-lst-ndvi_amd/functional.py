@@ -314,7 +314,8 @@ class ConvBNReLU(torch.autograd.Function):
             if E:
                 if ctx.needs_input_grad[1]:
                     demb = torch.empty((N, E), **f32)
-                    call("mau_bcast_bwd", dfull.data_ptr(), ldd, st.C0, demb.data_ptr(), code, N, H * W, E, stream)
+                    ws = torch.empty(lib.mau_bcast_bwd_ws_elems(N, H * W, E), **f32)
+                    call("mau_bcast_bwd", dfull.data_ptr(), ldd, st.C0, demb.data_ptr(), ws.data_ptr(), code, N, H * W, E, stream)
                 if ctx.needs_input_grad[0]:
                     dx = dfull[..., :pad8(st.C0)]            # C0 % 8 == 0 is enforced by the kernel when E > 0
             else:
@@ -472,7 +473,8 @@ class BcastCat(torch.autograd.Function):
         dx = torch.empty((N, H, W, pad8(C)), dtype=g.dtype, device=g.device)
         call("mau_copy_channels", g.data_ptr(), _ld(g), dx.data_ptr(), pad8(C), 0, pad8(C), code, N * H * W, C, stream)
         demb = torch.empty((N, E), dtype=torch.float32, device=g.device)
-        call("mau_bcast_bwd", g.data_ptr(), _ld(g), C, demb.data_ptr(), code, N, H * W, E, stream)
+        ws = torch.empty(lib.mau_bcast_bwd_ws_elems(N, H * W, E), dtype=torch.float32, device=g.device)
+        call("mau_bcast_bwd", g.data_ptr(), _ld(g), C, demb.data_ptr(), ws.data_ptr(), code, N, H * W, E, stream)
         return dx, None, demb
 
 
