@@ -42,9 +42,12 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lo, int hi_delta)
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int BCO>
-__global__ __launch_bounds__(BCO * 4) void wgrad_bf16_kernel(WgradP p, int nsplit) {
-  constexpr int NW = BCO / 16;                       // waves: (BCO/32) x 2
+// KG = number of wave groups that split the K (pixel) range of every stage between them: KG = 2 gives the
+// 64-channel variant 8 waves (two per SIMD) instead of 4; each group keeps its own accumulators and writes
+// its own partial slab (the split-sum downstream adds them like any other split).
+template <int BCO, int KG>
+__global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int nsplit) {
+  constexpr int NW = BCO / 16 * KG;                  // waves: (BCO/32) x 2 x KG
   constexpr int WCO = BCO / 32;
   constexpr int DYROW = BCO * 2;                     // bytes per dY row
   constexpr int DY_CPR = BCO / 8;                    // 16-byte chunks per dY row
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(BCO * 4) void wgrad_bf16_kernel(WgradP p, int nspli
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wco = wave % WCO, wci = wave / WCO;
+  const int wco = wave % WCO, wci = (wave / WCO) & 1, kg = wave / (2 * WCO);
   const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
   const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(p.x);
   const bf16* __restrict__ dyg = reinterpret_cast<const bf16*>(p.dy);
@@ -126,14 +129,15 @@ __global__ __launch_bounds__(BCO * 4) void wgrad_bf16_kernel(WgradP p, int nspli
   const int a_off = a_row0 * DYROW + 16 * (a_chunk ^ (BCO == 64 ? swz128(a_row0) : swz256(a_row0))) + 8 * (tp & 1);
   // B (X halo): row = (trow+dy)*18 + dx + 8h + 4s + q; (row>>1)&1 depends on ((trow+dy)&1, dx, q)
   const int b_chunk = wci * 4 + 2 * tg + (tp >> 1);
-  int b_off[2][9];
+  // address = (lane_base ^ swizzle_bit6) + row constants: the swizzle only toggles byte-offset bit 6 and
+  // depends on ((trow+dy)&1, dx, q) -> 6 per-lane bases (dx = 0..2, parity c = 0..1); everything else is an
+  // immediate (multiples of the 128-byte row).
+  const int b_lane = DY_BYTES + (8 * th + tq) * XROW + 16 * b_chunk + 8 * (tp & 1);
+  int b_base[3][2];
 #pragma unroll
-  for (int par = 0; par < 2; ++par)
+  for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int row = (par + tap / 3) * HW_ + tap % 3 + 8 * th + tq;      // trow = par (mod 2): 2*18 rows keep row mod 4
-      b_off[par][tap] = DY_BYTES + ((tap / 3) * HW_ + tap % 3 + 8 * th + tq) * XROW + 16 * (b_chunk ^ swz128(row)) + 8 * (tp & 1);
-    }
+    for (int c = 0; c < 2; ++c) b_base[dx][c] = b_lane ^ (((((dx + tq) >> 1) ^ c) & 1) << 6);
 
   f32x16 acc[9];
 #pragma unroll
@@ -152,13 +156,16 @@ __global__ __launch_bounds__(BCO * 4) void wgrad_bf16_kernel(WgradP p, int nspli
     for (int tile = t0; tile < t1; ++tile) {
       if (tile + 1 < t1) issue(stage ^ 1, tile + 1);
       const unsigned char* sb = smem + stage * STAGE;
-#pragma unroll 2
-      for (int trow = 0; trow < TH; ++trow) {
-        const bf16x8 a = tr_pair(sb + a_off + trow * 16 * DYROW, 4 * DYROW);
-        const unsigned char* xb = sb + trow * HW_ * XROW;
+      constexpr int ROWS = TH / KG;                    // tile rows of this wave group
+      const unsigned char* sbk = sb + kg * ROWS * HW_ * XROW;
+      const unsigned char* sak = sb + a_off + kg * ROWS * 16 * DYROW;
+#pragma unroll
+      for (int tr = 0; tr < ROWS; ++tr) {              // (trow = kg*ROWS + tr; ROWS is even, so parity(trow) = parity(tr))
+        const bf16x8 a = tr_pair(sak + tr * 16 * DYROW, 4 * DYROW);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const bf16x8 b = tr_pair(xb + ((trow & 1) ? b_off[1][tap] : b_off[0][tap]), 4 * XROW);
+          const int dy = tap / 3, dx = tap % 3;
+          const bf16x8 b = tr_pair(sbk + b_base[dx][(tr + dy) & 1] + ((tr + dy) * HW_ + dx) * XROW, 4 * XROW);
           acc[tap] = mfma32(a, b, acc[tap]);
         }
       }
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(BCO * 4) void wgrad_bf16_kernel(WgradP p, int nspli
   }
 
   // ---- partial slab: [split][tap][CoutPad][CinPad], 128 contiguous bytes per half-wave ----
-  float* out = p.acc + (size_t)split * 9 * p.CoutPad * p.CinPad;
+  float* out = p.acc + (size_t)(split * KG + kg) * 9 * p.CoutPad * p.CinPad;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -179,18 +186,18 @@ __global__ __launch_bounds__(BCO * 4) void wgrad_bf16_kernel(WgradP p, int nspli
     }
 }
 
-template <int BCO>
+template <int BCO, int KG>
 static int launch(const WgradP& p, int nsplit, hipStream_t st) {
   constexpr int DY_Q = TH * TW * (BCO / 8) / 64;
   constexpr int X_Q = (HALO * 8 + 63) / 64;
   constexpr size_t lds = 2 * (size_t)(DY_Q + X_Q) * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<BCO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<BCO, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(nsplit, p.CoutPad / BCO, p.CinPad / BCI);
-  MAU_LAUNCH(wgrad_bf16_kernel<BCO>, grid, dim3(BCO * 4), lds, st, p, nsplit);
+  dim3 grid(nsplit / KG, p.CoutPad / BCO, p.CinPad / BCI);      // nsplit counts slabs: KG per workgroup
+  MAU_LAUNCH((wgrad_bf16_kernel<BCO, KG>), grid, dim3(BCO * 4 * KG), lds, st, p, nsplit / KG);
   return check_launch("wgrad_bf16_kernel");
 }
 }  // namespace wg2
@@ -210,19 +217,21 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   if (smax < 1) smax = 1;
   if (smax > 1024) smax = 1024;
   if ((size_t)smax > cap) smax = (int)cap;
+  const int kg = bco == 64 ? 2 : 1;                // slabs written per workgroup (wave groups splitting K)
   int best = 1;
   double best_score = -1.0;
-  for (int s = 1; s <= smax; ++s) {
+  for (int s = 1; s <= smax; ++s) {                // s = workgroups along the split axis
+    if ((size_t)s * kg > cap) break;
     const long blocks = (long)outTiles * s;
     const long rounds = (blocks + 255) / 256;
     const double eff = (double)blocks / (double)(rounds * 256);
-    const double score = eff - 0.0015 * s;
+    const double score = eff - 0.0015 * s * kg;
     if (score > best_score + 1e-9) {
       best_score = score;
       best = s;
     }
   }
-  return best;
+  return best * kg;
 }
 
 int launch_wgrad_bf16_v2(const WgradP& p, hipStream_t st) {
@@ -231,8 +240,8 @@ int launch_wgrad_bf16_v2(const WgradP& p, hipStream_t st) {
   q.tilesX = ceil_div(p.W, wg2::TW);
   q.tilesY = ceil_div(p.H, wg2::TH);
   q.nTiles = p.N * q.tilesX * q.tilesY;
-  if (p.CoutPad % 128 == 0) return wg2::launch<128>(q, nsplit, st);
-  return wg2::launch<64>(q, nsplit, st);
+  if (p.CoutPad % 128 == 0) return wg2::launch<128, 1>(q, nsplit, st);
+  return wg2::launch<64, 2>(q, nsplit, st);
 }
 
 }  // namespace mau
