@@ -107,7 +107,8 @@ def main():
     ap.add_argument("--meta", type=int, default=4)
     ap.add_argument("--no-sync-bn", action="store_true", help="per-GPU BatchNorm statistics (reference semantics per device)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (profiles/)")
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; default: the "
+                         "figure committed in profiles/r1/dominant_kernel_summary.json (same workload)")
     args = ap.parse_args()
 
     import mau_amd
@@ -205,10 +206,18 @@ def main():
         return
 
     conv = timer.summary()
+    traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
+    if traffic is None and args.precision == "bf16" and args.model_type == "unet" and not args.infer and B == 32 and S == 256:
+        try:   # PMC counters cannot be read inside this process: use the committed separate-pass measurement
+            with open(os.path.join(ROOT, "profiles", "r1", "dominant_kernel_summary.json")) as f:
+                traffic = json.load(f)["conv3x3_bf16_kernel (dominant: forward + data gradient)"]["hbm_bytes_per_launch_pmc"]
+            traffic_src = "profiles/r1/dominant_kernel_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"
+        except (OSError, KeyError, ValueError):
+            traffic = None
     peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
     achieved = conv["total_flop"] / (conv["total_ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": args.traffic_bytes,
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                 "kernel": "conv3x3_igemm_kernel (forward + data-gradient launches)",
                 "launches": conv["launches"], "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
                 "flop_per_launch_avg": conv["total_flop"] / conv["launches"],
