@@ -5,6 +5,7 @@
 // Backward:             bn_relu_bwd_reduce (partials) -> reduce_rows -> [all-reduce] -> bn_relu_bwd_apply
 // All reductions are slab + fixed-order second stage: bitwise reproducible, no float atomics.
 // All of these kernels are HBM-streaming: 16-byte (bf16) / 32-byte (f32) vectors per lane.
+#include <stdlib.h>
 #include "mau_common.h"
 
 namespace mau {
@@ -105,9 +106,14 @@ struct PixVec {
     ps = threadIdx.x / nvl;
   }
 };
-static inline int pixvec_pixels_per_block(int nv) {
+// pixels per workgroup: 8..32 pixels per thread (the per-channel coefficient set-up is amortised over
+// them) while keeping at least ~2048 workgroups in flight for the chip
+static inline int pixvec_pixels_per_block(int nv, int64_t npix, int max_per_thread) {
   const int nvl = nv < 256 ? nv : 256;
-  return (256 / nvl) * 8;          // 8 pixels per thread
+  const int ps = 256 / nvl;
+  int per_thread = max_per_thread;
+  while (per_thread > 8 && npix / ((int64_t)ps * per_thread) < 2048) per_thread >>= 1;
+  return ps * per_thread;
 }
 
 template <typename T>
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
   }
 }
 
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ y,
                                                                 int ldy, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
@@ -256,8 +262,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
       F8 g[4], v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        g[u] = load8<T>(da + (pix + u * m.PS) * ldda + c);
-        v[u] = load8<T>(y + (pix + u * m.PS) * ldy + c);
+        g[u] = NT ? load8_nt<T>(da + (pix + u * m.PS) * ldda + c) : load8<T>(da + (pix + u * m.PS) * ldda + c);
+        v[u] = NT ? load8_nt<T>(y + (pix + u * m.PS) * ldy + c) : load8<T>(y + (pix + u * m.PS) * ldy + c);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
           const float dz = act > 0.f ? g[u].v[j] : 0.f;
           o.v[j] = fmaf(sc[j], dz, -fmaf(k1[j], v[u].v[j], k0[j]));
         }
-        store8<T>(dy + (pix + u * m.PS) * lddy + c, o);
+        if (NT) store8_nt<T>(dy + (pix + u * m.PS) * lddy + c, o); else store8<T>(dy + (pix + u * m.PS) * lddy + c, o);
       }
     }
     for (; pix < p1; pix += m.PS) {
@@ -327,7 +333,7 @@ int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* s
   MAU_REQUIRE(y && a && scale && shift && npix > 0 && C > 0, "bn_relu_apply: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && lda % 8 == 0 && ldy >= C8 && lda >= C8, "bn_relu_apply: bad ld");
-  const int pixb = pixvec_pixels_per_block(C8 / 8);
+  const int pixb = pixvec_pixels_per_block(C8 / 8, npix, 8);
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bn_relu_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)y, ldy, scale, shift, (T*)a, lda, npix, C, C8, pixb));
   return check_launch("bn_relu_apply_kernel");
@@ -353,8 +359,15 @@ int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, cons
   MAU_REQUIRE(da && y && dy && sums && npix > 0 && C > 0 && count > 0, "bn_relu_bwd_apply: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && lddy >= C8, "bn_relu_bwd_apply: bad ld");
-  const int pixb = pixvec_pixels_per_block(C8 / 8);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bn_relu_bwd_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
+  const int pixb = pixvec_pixels_per_block(C8 / 8, npix, 32);
+  static const bool nt = getenv("MAU_BN_NT") ? atoi(getenv("MAU_BN_NT")) != 0 : false;
+  if (nt) {
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((bn_relu_bwd_apply_kernel<T, true>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, sums,
+                                         1.0 / count, (T*)dy, lddy, npix, C, C8, pixb));
+    return check_launch("bn_relu_bwd_apply_kernel");
+  }
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((bn_relu_bwd_apply_kernel<T, false>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, sums,
                                                1.0 / count, (T*)dy, lddy, npix, C, C8, pixb));
   return check_launch("bn_relu_bwd_apply_kernel");

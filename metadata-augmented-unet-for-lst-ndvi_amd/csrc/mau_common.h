@@ -84,6 +84,50 @@ __device__ __forceinline__ void store8<bf16>(bf16* p, const F8& r) {
   *reinterpret_cast<bf16x8*>(p) = a;
 }
 
+// non-temporal (streaming) variants for data touched exactly once by a kernel
+template <typename T>
+__device__ __forceinline__ F8 load8_nt(const T* p);
+template <>
+__device__ __forceinline__ F8 load8_nt<float>(const float* p) {
+  F8 r;
+  const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[i] = a[i];
+    r.v[4 + i] = b[i];
+  }
+  return r;
+}
+template <>
+__device__ __forceinline__ F8 load8_nt<bf16>(const bf16* p) {
+  F8 r;
+  const bf16x8 a = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store8_nt(T* p, const F8& r);
+template <>
+__device__ __forceinline__ void store8_nt<float>(float* p, const F8& r) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = r.v[i];
+    b[i] = r.v[4 + i];
+  }
+  __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p));
+  __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p + 4));
+}
+template <>
+__device__ __forceinline__ void store8_nt<bf16>(bf16* p, const F8& r) {
+  bf16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (bf16)r.v[i];
+  __builtin_nontemporal_store(a, reinterpret_cast<bf16x8*>(p));
+}
+
 __device__ __forceinline__ F8 zero8() {
   F8 r;
 #pragma unroll
