@@ -45,60 +45,51 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
 }
 
 // ---- MaxPool2d(2,2), floor mode -------------------------------------------------------------
+// grid = (x-chunks of the output row, output rows, images): no 64-bit div/mod per element
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N,
-                                                          int H, int W, int C8) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int H, int W,
+                                                          int C8) {
   const int Ho = H / 2, Wo = W / 2, nv = C8 >> 3;
-  const int64_t total = (int64_t)N * Ho * Wo * nv;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % nv) * 8;
-    int64_t t = idx / nv;
-    const int xo = t % Wo;
-    t /= Wo;
-    const int yo = t % Ho;
-    const int n = (int)(t / Ho);
-    const T* b = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * ldx + c;
-    const F8 v00 = load8<T>(b), v01 = load8<T>(b + ldx), v10 = load8<T>(b + (size_t)W * ldx), v11 = load8<T>(b + (size_t)W * ldx + ldx);
-    F8 o;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wo * nv) return;
+  const int xo = idx / nv, c = (idx - xo * nv) * 8;
+  const int yo = blockIdx.y, n = blockIdx.z;
+  const T* b = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * ldx + c;
+  const F8 v00 = load8<T>(b), v01 = load8<T>(b + ldx), v10 = load8<T>(b + (size_t)W * ldx), v11 = load8<T>(b + (size_t)W * ldx + ldx);
+  F8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.v[j] = fmaxf(fmaxf(v00.v[j], v01.v[j]), fmaxf(v10.v[j], v11.v[j]));
-    store8<T>(y + (((size_t)n * Ho + yo) * Wo + xo) * ldy + c, o);
-  }
+  for (int j = 0; j < 8; ++j) o.v[j] = fmaxf(fmaxf(v00.v[j], v01.v[j]), fmaxf(v10.v[j], v11.v[j]));
+  store8<T>(y + (((size_t)n * Ho + yo) * Wo + xo) * ldy + c, o);
 }
 
 // one thread per INPUT pixel vector: grad goes to the first maximum of the window (scan order
 // (0,0),(0,1),(1,0),(1,1) with strict '>' as ATen's max_pool2d), uncovered odd rows/cols get 0.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
-                                                          T* __restrict__ dx, int lddx, int N, int H, int W, int C8) {
+                                                          T* __restrict__ dx, int lddx, int H, int W, int C8) {
   const int Ho = H / 2, Wo = W / 2, nv = C8 >> 3;
-  const int64_t total = (int64_t)N * H * W * nv;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % nv) * 8;
-    int64_t t = idx / nv;
-    const int xi = t % W;
-    t /= W;
-    const int yi = t % H;
-    const int n = (int)(t / H);
-    F8 o = zero8();
-    const int yo = yi >> 1, xo = xi >> 1;
-    if (yo < Ho && xo < Wo) {
-      const T* b = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * ldx + c;
-      const F8 v00 = load8<T>(b), v01 = load8<T>(b + ldx), v10 = load8<T>(b + (size_t)W * ldx), v11 = load8<T>(b + (size_t)W * ldx + ldx);
-      const F8 g = load8<T>(dy + (((size_t)n * Ho + yo) * Wo + xo) * lddy + c);
-      const int me = (yi & 1) * 2 + (xi & 1);
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= W * nv) return;
+  const int xi = idx / nv, c = (idx - xi * nv) * 8;
+  const int yi = blockIdx.y, n = blockIdx.z;
+  F8 o = zero8();
+  const int yo = yi >> 1, xo = xi >> 1;
+  if (yo < Ho && xo < Wo) {
+    const T* b = x + (((size_t)n * H + 2 * yo) * W + 2 * xo) * ldx + c;
+    const F8 v00 = load8<T>(b), v01 = load8<T>(b + ldx), v10 = load8<T>(b + (size_t)W * ldx), v11 = load8<T>(b + (size_t)W * ldx + ldx);
+    const F8 g = load8<T>(dy + (((size_t)n * Ho + yo) * Wo + xo) * lddy + c);
+    const int me = (yi & 1) * 2 + (xi & 1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int arg = 0;
-        float m = v00.v[j];
-        if (v01.v[j] > m) { m = v01.v[j]; arg = 1; }
-        if (v10.v[j] > m) { m = v10.v[j]; arg = 2; }
-        if (v11.v[j] > m) { m = v11.v[j]; arg = 3; }
-        o.v[j] = (arg == me) ? g.v[j] : 0.f;
-      }
+    for (int j = 0; j < 8; ++j) {
+      int arg = 0;
+      float m = v00.v[j];
+      if (v01.v[j] > m) { m = v01.v[j]; arg = 1; }
+      if (v10.v[j] > m) { m = v10.v[j]; arg = 2; }
+      if (v11.v[j] > m) { m = v11.v[j]; arg = 3; }
+      o.v[j] = (arg == me) ? g.v[j] : 0.f;
     }
-    store8<T>(dx + (((size_t)n * H + yi) * W + xi) * lddx + c, o);
   }
+  store8<T>(dx + (((size_t)n * H + yi) * W + xi) * lddx + c, o);
 }
 
 // ---- bilinear, align_corners=True ------------------------------------------------------------
@@ -114,88 +105,79 @@ __device__ __forceinline__ void ac_src(float scale, int dst, int in, int& i0, in
   l0 = 1.f - l1;
 }
 
+// grid = (x-chunks of the destination row, destination rows, images); the row's (y0, y1, ly) are block-uniform
 template <typename T>
 __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ src, int ldsrc, int h, int w, T* __restrict__ dst,
-                                                         int lddst, int choff, int N, int H, int W, int C8) {
+                                                         int lddst, int choff, int H, int W, int C8) {
   const int nv = C8 >> 3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= W * nv) return;
+  const int xo = idx / nv, c = (idx - xo * nv) * 8;
+  const int yo = blockIdx.y, n = blockIdx.z;
   const float sy = ac_scale(h, H), sx = ac_scale(w, W);
-  const int64_t total = (int64_t)N * H * W * nv;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % nv) * 8;
-    int64_t t = idx / nv;
-    const int xo = t % W;
-    t /= W;
-    const int yo = t % H;
-    const int n = (int)(t / H);
-    int y0, y1, x0, x1;
-    float ly0, ly1, lx0, lx1;
-    ac_src(sy, yo, h, y0, y1, ly0, ly1);
-    ac_src(sx, xo, w, x0, x1, lx0, lx1);
-    const T* b = src + (size_t)n * h * w * ldsrc + c;
-    const F8 v00 = load8<T>(b + ((size_t)y0 * w + x0) * ldsrc), v01 = load8<T>(b + ((size_t)y0 * w + x1) * ldsrc);
-    const F8 v10 = load8<T>(b + ((size_t)y1 * w + x0) * ldsrc), v11 = load8<T>(b + ((size_t)y1 * w + x1) * ldsrc);
-    F8 o;
+  int y0, y1, x0, x1;
+  float ly0, ly1, lx0, lx1;
+  ac_src(sy, yo, h, y0, y1, ly0, ly1);
+  ac_src(sx, xo, w, x0, x1, lx0, lx1);
+  const T* b = src + (size_t)n * h * w * ldsrc + c;
+  const F8 v00 = load8<T>(b + ((size_t)y0 * w + x0) * ldsrc), v01 = load8<T>(b + ((size_t)y0 * w + x1) * ldsrc);
+  const F8 v10 = load8<T>(b + ((size_t)y1 * w + x0) * ldsrc), v11 = load8<T>(b + ((size_t)y1 * w + x1) * ldsrc);
+  F8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      o.v[j] = ly0 * (lx0 * v00.v[j] + lx1 * v01.v[j]) + ly1 * (lx0 * v10.v[j] + lx1 * v11.v[j]);
-    store8<T>(dst + (((size_t)n * H + yo) * W + xo) * lddst + choff + c, o);
-  }
+  for (int j = 0; j < 8; ++j)
+    o.v[j] = ly0 * (lx0 * v00.v[j] + lx1 * v01.v[j]) + ly1 * (lx0 * v10.v[j] + lx1 * v11.v[j]);
+  store8<T>(dst + (((size_t)n * H + yo) * W + xo) * lddst + choff + c, o);
 }
 
 // adjoint in gather form: every source pixel sums the destination pixels that read it, with the
-// same (i0, i1, l0, l1) arithmetic as the forward pass.
+// same (i0, i1, l0, l1) arithmetic as the forward pass.  grid = (x-chunks of the source row, source rows, images)
 template <typename T>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ ddst, int ldddst, int choff, int H, int W,
-                                                         T* __restrict__ dsrc, int lddsrc, int N, int h, int w, int C8) {
+                                                         T* __restrict__ dsrc, int lddsrc, int h, int w, int C8) {
   const int nv = C8 >> 3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= w * nv) return;
+  const int xi = idx / nv, c = (idx - xi * nv) * 8;
+  const int yi = blockIdx.y, n = blockIdx.z;
   const float sy = ac_scale(h, H), sx = ac_scale(w, W);
-  const int64_t total = (int64_t)N * h * w * nv;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % nv) * 8;
-    int64_t t = idx / nv;
-    const int xi = t % w;
-    t /= w;
-    const int yi = t % h;
-    const int n = (int)(t / h);
-    // destination rows/cols whose source interval can touch (yi, xi): |s*j - i| < 1 (loose bounds, exact test inside)
-    int ja = 0, jb = H - 1, ka = 0, kb = W - 1;
-    if (sy > 0.f) {
-      ja = (int)floorf(((float)yi - 1.f) / sy) - 1;
-      jb = (int)ceilf(((float)yi + 1.f) / sy) + 1;
-      if (ja < 0) ja = 0;
-      if (jb > H - 1) jb = H - 1;
-    }
-    if (sx > 0.f) {
-      ka = (int)floorf(((float)xi - 1.f) / sx) - 1;
-      kb = (int)ceilf(((float)xi + 1.f) / sx) + 1;
-      if (ka < 0) ka = 0;
-      if (kb > W - 1) kb = W - 1;
-    }
-    F8 acc = zero8();
-    for (int j = ja; j <= jb; ++j) {
-      int y0, y1;
-      float ly0, ly1;
-      ac_src(sy, j, h, y0, y1, ly0, ly1);
-      float wy = 0.f;
-      if (y0 == yi) wy += ly0;
-      if (y1 == yi) wy += ly1;
-      if (wy == 0.f && y0 != yi && y1 != yi) continue;
-      for (int k = ka; k <= kb; ++k) {
-        int x0, x1;
-        float lx0, lx1;
-        ac_src(sx, k, w, x0, x1, lx0, lx1);
-        float wx = 0.f;
-        if (x0 == xi) wx += lx0;
-        if (x1 == xi) wx += lx1;
-        if (x0 != xi && x1 != xi) continue;
-        const F8 g = load8<T>(ddst + (((size_t)n * H + j) * W + k) * ldddst + choff + c);
-        const float wgt = wy * wx;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc.v[q] = fmaf(wgt, g.v[q], acc.v[q]);
-      }
-    }
-    store8<T>(dsrc + (((size_t)n * h + yi) * w + xi) * lddsrc + c, acc);
+  // destination rows/cols whose source interval can touch (yi, xi): |s*j - i| < 1 (loose bounds, exact test inside)
+  int ja = 0, jb = H - 1, ka = 0, kb = W - 1;
+  if (sy > 0.f) {
+    ja = (int)floorf(((float)yi - 1.f) / sy) - 1;
+    jb = (int)ceilf(((float)yi + 1.f) / sy) + 1;
+    if (ja < 0) ja = 0;
+    if (jb > H - 1) jb = H - 1;
   }
+  if (sx > 0.f) {
+    ka = (int)floorf(((float)xi - 1.f) / sx) - 1;
+    kb = (int)ceilf(((float)xi + 1.f) / sx) + 1;
+    if (ka < 0) ka = 0;
+    if (kb > W - 1) kb = W - 1;
+  }
+  F8 acc = zero8();
+  for (int j = ja; j <= jb; ++j) {
+    int y0, y1;
+    float ly0, ly1;
+    ac_src(sy, j, h, y0, y1, ly0, ly1);
+    if (y0 != yi && y1 != yi) continue;
+    float wy = 0.f;
+    if (y0 == yi) wy += ly0;
+    if (y1 == yi) wy += ly1;
+    for (int k = ka; k <= kb; ++k) {
+      int x0, x1;
+      float lx0, lx1;
+      ac_src(sx, k, w, x0, x1, lx0, lx1);
+      if (x0 != xi && x1 != xi) continue;
+      float wx = 0.f;
+      if (x0 == xi) wx += lx0;
+      if (x1 == xi) wx += lx1;
+      const F8 g = load8<T>(ddst + (((size_t)n * H + j) * W + k) * ldddst + choff + c);
+      const float wgt = wy * wx;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc.v[q] = fmaf(wgt, g.v[q], acc.v[q]);
+    }
+  }
+  store8<T>(dsrc + (((size_t)n * h + yi) * w + xi) * lddsrc + c, acc);
 }
 
 // dst[..., choff + c] = src[..., c] for c < C (element granularity: tolerates any C / choff), then
@@ -211,15 +193,26 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const T* __restrict_
     dst[pix * lddst + choff + c] = c < C ? src[pix * ldsrc + c] : (T)0.f;
   }
 }
+// vector path: a thread owns one 8-channel vector column and walks pixels (no div/mod per element)
 template <typename T>
 __global__ __launch_bounds__(256) void copy_channels_vec_kernel(const T* __restrict__ src, int ldsrc, T* __restrict__ dst,
-                                                                int lddst, int choff, int64_t npix, int C8) {
+                                                                int lddst, int choff, int64_t npix, int C8, int pixb) {
   const int nv = C8 >> 3;
-  const int64_t total = npix * nv;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t pix = idx / nv;
-    const int c = (int)(idx % nv) * 8;
-    store8<T>(dst + pix * lddst + choff + c, load8<T>(src + pix * ldsrc + c));
+  const int nvl = nv < 256 ? nv : 256, PS = 256 / nvl;
+  const int v = threadIdx.x % nvl, ps = threadIdx.x / nvl;
+  if (ps >= PS) return;
+  const int64_t p0 = (int64_t)blockIdx.x * pixb, p1 = p0 + pixb < npix ? p0 + pixb : npix;
+  for (int vv = v; vv < nv; vv += nvl) {
+    const int c = vv * 8;
+    int64_t pix = p0 + ps;
+    for (; pix + 3 * PS < p1; pix += 4 * PS) {
+      F8 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = load8<T>(src + (pix + u * PS) * ldsrc + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) store8<T>(dst + (pix + u * PS) * lddst + choff + c, t[u]);
+    }
+    for (; pix < p1; pix += PS) store8<T>(dst + pix * lddst + choff + c, load8<T>(src + pix * ldsrc + c));
   }
 }
 
@@ -330,8 +323,9 @@ int mau_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int 
   MAU_REQUIRE(x && y && N > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2x2_fwd: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C8 && ldy >= C8, "maxpool2x2_fwd: bad ld");
-  const int grid = stream_grid((int64_t)N * (H / 2) * (W / 2) * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(maxpool_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, N, H, W, C8));
+  MAU_REQUIRE(H / 2 <= 65535 && N <= 65535, "maxpool2x2_fwd: H/2 and N must fit a grid dimension");
+  dim3 grid(ceil_div((W / 2) * (C8 / 8), 256), H / 2, N);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(maxpool_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, H, W, C8));
   return check_launch("maxpool_fwd_kernel");
 }
 
@@ -340,8 +334,9 @@ int mau_maxpool2x2_bwd(const void* x, int ldx, const void* dy, int lddy, void* d
   MAU_REQUIRE(x && dy && dx && N > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2x2_bwd: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldx >= C8 && lddy >= C8 && lddx >= C8, "maxpool2x2_bwd: bad ld");
-  const int grid = stream_grid((int64_t)N * H * W * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(maxpool_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C8));
+  MAU_REQUIRE(H <= 65535 && N <= 65535, "maxpool2x2_bwd: H and N must fit a grid dimension");
+  dim3 grid(ceil_div(W * (C8 / 8), 256), H, N);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(maxpool_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, H, W, C8));
   return check_launch("maxpool_bwd_kernel");
 }
 
@@ -350,8 +345,9 @@ int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst,
   MAU_REQUIRE(src && dst && N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, "resize_bilinear_fwd: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldsrc % 8 == 0 && lddst % 8 == 0 && choff % 8 == 0 && ldsrc >= C8 && lddst >= choff + C8, "resize_bilinear_fwd: bad ld/choff");
-  const int grid = stream_grid((int64_t)N * H * W * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, N, H, W, C8));
+  MAU_REQUIRE(H <= 65535 && N <= 65535, "resize_bilinear_fwd: H and N must fit a grid dimension");
+  dim3 grid(ceil_div(W * (C8 / 8), 256), H, N);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, H, W, C8));
   return check_launch("resize_fwd_kernel");
 }
 
@@ -360,8 +356,9 @@ int mau_resize_bilinear_bwd(const void* ddst, int ldddst, int choff, int H, int 
   MAU_REQUIRE(ddst && dsrc && N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, "resize_bilinear_bwd: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldddst % 8 == 0 && lddsrc % 8 == 0 && choff % 8 == 0 && lddsrc >= C8 && ldddst >= choff + C8, "resize_bilinear_bwd: bad ld/choff");
-  const int grid = stream_grid((int64_t)N * h * w * (C8 / 8), 256);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_bwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)ddst, ldddst, choff, H, W, (T*)dsrc, lddsrc, N, h, w, C8));
+  MAU_REQUIRE(h <= 65535 && N <= 65535, "resize_bilinear_bwd: h and N must fit a grid dimension");
+  dim3 grid(ceil_div(w * (C8 / 8), 256), h, N);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)ddst, ldddst, choff, H, W, (T*)dsrc, lddsrc, h, w, C8));
   return check_launch("resize_bwd_kernel");
 }
 
@@ -371,8 +368,9 @@ int mau_copy_channels(const void* src, int ldsrc, void* dst, int lddst, int chof
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (C % 8 == 0) && (choff % 8 == 0) && (ldsrc % 8 == 0) && (lddst % 8 == 0) && zero_to <= choff + C;
   if (vec) {
-    const int grid = stream_grid(npix * (C / 8), 256);
-    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(copy_channels_vec_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)src, ldsrc, (T*)dst, lddst, choff, npix, C));
+    const int nv = C / 8, nvl = nv < 256 ? nv : 256;
+    const int pixb = (256 / nvl) * 8;
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(copy_channels_vec_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, st, (const T*)src, ldsrc, (T*)dst, lddst, choff, npix, C, pixb));
   } else {
     const int span = (zero_to > choff + C ? zero_to : choff + C) - choff;
     const int grid = stream_grid(npix * span, 256);
