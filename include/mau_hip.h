@@ -114,6 +114,13 @@ int mau_bn_finalize_train(const double* sums, double count, const float* gamma, 
                           float* running_mean, float* running_var, int64_t* num_batches_tracked,
                           float momentum, float eps, float* scale, float* shift, float* mean,
                           float* invstd, int C, mau_stream_t stream);
+/* Single-GPU training shortcut: conv slab [rows][2*Cout64] -> (fp64 partials in `ws`,
+ * mau_bn_stats_ws_elems(rows, C) elements) -> the outputs of mau_bn_finalize_train, in two launches. */
+size_t mau_bn_stats_ws_elems(int rows, int C);
+int mau_bn_stats_finalize_train(const float* slab, int rows, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                                double* ws, int C, mau_stream_t stream);
 /* Eval mode: scale/shift from the running statistics (mean/invstd outputs optional, may be NULL). */
 int mau_bn_coeffs_eval(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, float* mean,

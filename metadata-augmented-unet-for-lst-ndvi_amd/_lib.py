@@ -42,6 +42,8 @@ PROTOTYPES = {
     "mau_reduce_rows_f64": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "mau_reduce_rows_f32": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "mau_bn_finalize_train": (_i, [_p, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
+    "mau_bn_stats_ws_elems": (_sz, [_i, _i]),
+    "mau_bn_stats_finalize_train": (_i, [_p, _i, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i, _p]),
     "mau_bn_coeffs_eval": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p]),
     "mau_bn_relu_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _i64, _i, _p]),
     "mau_bn_relu_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),

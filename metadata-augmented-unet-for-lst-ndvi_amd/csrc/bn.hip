@@ -80,6 +80,38 @@ __global__ void bn_finalize_train_kernel(const double* __restrict__ sums, double
   }
 }
 
+// Fused second level of the statistics reduce + finalize (single-GPU training): partial fp64 sums
+// [chunks][2*ldp] (column c: sum, column ldp + c: sum of squares) -> the same outputs as
+// bn_finalize_train_kernel.  One thread per channel, chunks added in fixed order.
+__global__ void bn_finalize_from_partials_kernel(const double* __restrict__ part, int chunks, int ldp, double count,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float* __restrict__ rmean, float* __restrict__ rvar, int64_t* nbt, float momentum,
+                                                 float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                 float* __restrict__ mean_o, float* __restrict__ invstd_o, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    s += part[(size_t)k * 2 * ldp + c];
+    q += part[(size_t)k * 2 * ldp + ldp + c];
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_o[c] = (float)mean;
+  invstd_o[c] = invstd;
+  if (rmean) {
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+  }
+}
+
 __global__ void bn_coeffs_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_o,
@@ -318,6 +350,23 @@ int mau_bn_finalize_train(const double* sums, double count, const float* gamma, 
   MAU_LAUNCH(bn_finalize_train_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
                      beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd, C);
   return check_launch("bn_finalize_train_kernel");
+}
+
+size_t mau_bn_stats_ws_elems(int rows, int C) { return (size_t)reduce_chunks(rows) * 2 * round_up(C, 64); }
+
+int mau_bn_stats_finalize_train(const float* slab, int rows, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                                float* scale, float* shift, float* mean, float* invstd, double* ws, int C, mau_stream_t stream) {
+  MAU_REQUIRE(slab && ws && gamma && beta && scale && shift && mean && invstd && rows > 0 && C > 0 && count > 0, "bn_stats_finalize_train: bad arguments");
+  MAU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize_train: running_mean/var must come together");
+  hipStream_t st = (hipStream_t)stream;
+  const int cpad = round_up(C, 64), M = 2 * cpad, chunks = reduce_chunks(rows);
+  // level 1: the conv epilogue's slab [rows][2*cpad] -> fp64 partials [chunks][2*cpad]
+  MAU_LAUNCH((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, M, ws, M);
+  // level 2 + finalize
+  MAU_LAUNCH(bn_finalize_from_partials_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)ws, chunks, cpad, count, gamma,
+             beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd, C);
+  return check_launch("bn_stats_finalize_train");
 }
 
 int mau_bn_coeffs_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

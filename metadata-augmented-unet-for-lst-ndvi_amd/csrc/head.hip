@@ -8,41 +8,62 @@ namespace mau {
 constexpr int HEAD_MAX_CO = 4;
 constexpr int HEAD_PIX_PER_BLOCK = 512;
 
-// One thread per pixel: the pixel's channel vector is read with 16-byte loads, the (tiny) weight
-// matrix sits in LDS (broadcast reads), the NCHW fp32 output is written fully coalesced.
+// 8 lanes per pixel: lane (pixel slot = tid/8, vector = tid%8) loads ONE 16-byte vector, so a wave reads
+// 8 pixels x 128 contiguous bytes per instruction; each lane keeps the weights of its 8 channels in
+// registers, three shuffle steps sum the 8 lanes, lane o writes output channel o (NCHW fp32).
 template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ a, int lda, const float* __restrict__ w,
                                                        const float* __restrict__ b, float* __restrict__ out, int tanh0, int HW,
                                                        int C, int Co, int64_t npix) {
-  extern __shared__ float wl[];             // [Co][C8]
-  const int C8 = (C + 7) & ~7;
-  for (int i = threadIdx.x; i < Co * C8; i += blockDim.x) {
-    const int o = i / C8, c = i % C8;
-    wl[i] = c < C ? w[o * C + c] : 0.f;
-  }
-  __syncthreads();
-  for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (int64_t)gridDim.x * blockDim.x) {
+  const int sub = threadIdx.x & 7;
+  const int nv = (C + 7) >> 3;
+  float wr[HEAD_MAX_CO][8];                 // weights of vector `sub` (valid when nv <= 8: the usual 64-channel head)
+#pragma unroll
+  for (int o = 0; o < HEAD_MAX_CO; ++o)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wr[o][j] = (o < Co && sub * 8 + j < C) ? w[o * C + sub * 8 + j] : 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 32;
+  for (int64_t pix0 = (int64_t)blockIdx.x * 32; pix0 < npix; pix0 += stride) {      // block-uniform trip count
+    const int64_t pix = pix0 + (threadIdx.x >> 3);
+    const bool live = pix < npix;
     float acc[HEAD_MAX_CO];
 #pragma unroll
     for (int o = 0; o < HEAD_MAX_CO; ++o) acc[o] = 0.f;
-    const T* src = a + pix * lda;
-    for (int c = 0; c < C8; c += 8) {
-      const F8 x = load8<T>(src + c);
+    if (live) {
+      if (sub < nv) {
+        const F8 x = load8<T>(a + pix * lda + sub * 8);
+#pragma unroll
+        for (int o = 0; o < HEAD_MAX_CO; ++o)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[o] = fmaf(x.v[j], wr[o][j], acc[o]);
+      }
+      for (int v = sub + 8; v < nv; v += 8) {       // heads wider than 64 channels: weights from memory
+        const F8 x = load8<T>(a + pix * lda + v * 8);
+#pragma unroll
+        for (int o = 0; o < HEAD_MAX_CO; ++o)
+          if (o < Co) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (v * 8 + j < C) acc[o] = fmaf(x.v[j], w[o * C + v * 8 + j], acc[o]);
+          }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < HEAD_MAX_CO; ++o) {
+      acc[o] += __shfl_xor(acc[o], 1);
+      acc[o] += __shfl_xor(acc[o], 2);
+      acc[o] += __shfl_xor(acc[o], 4);
+    }
+    if (live && sub < Co) {
+      float r = 0.f;
 #pragma unroll
       for (int o = 0; o < HEAD_MAX_CO; ++o)
-        if (o < Co) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[o] = fmaf(x.v[j], wl[o * C8 + c + j], acc[o]);
-        }
+        if (o == sub) r = acc[o];
+      r += b[sub];
+      if (tanh0 && sub == 0) r = tanhf(r);
+      const int64_t n = pix / HW, q = pix - n * HW;
+      out[((size_t)n * Co + sub) * HW + q] = r;
     }
-    const int64_t n = pix / HW, q = pix % HW;
-#pragma unroll
-    for (int o = 0; o < HEAD_MAX_CO; ++o)
-      if (o < Co) {
-        float r = acc[o] + b[o];
-        if (tanh0 && o == 0) r = tanhf(r);
-        out[((size_t)n * Co + o) * HW + q] = r;
-      }
   }
 }
 
@@ -74,8 +95,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, 
 #pragma unroll
       for (int j = 0; j < 8; ++j) wr[o][j] = (o < Co && c0 + j < C) ? w[o * C + c0 + j] : 0.f;
     if (c0 < C8) {
-      for (int64_t p = p0 + ps; p < p1; p += 32) {
-        const int64_t n = p / HW, q = p % HW;
+      int64_t n = (p0 + ps) / HW;
+      int q = (int)((p0 + ps) - n * HW);
+      for (int64_t p = p0 + ps; p < p1; p += 32, q += 32) {
+        while (q >= HW) {                       // advance (image, pixel-in-image) without a 64-bit division per pixel
+          q -= HW;
+          ++n;
+        }
         float dz[HEAD_MAX_CO];
 #pragma unroll
         for (int o = 0; o < HEAD_MAX_CO; ++o) {
@@ -245,10 +271,8 @@ int mau_head_fwd(const void* a, int lda, const float* w, const float* b, float* 
   MAU_REQUIRE(Co >= 1 && Co <= HEAD_MAX_CO, "head_fwd: out_channels must be in [1,%d]", HEAD_MAX_CO);
   MAU_REQUIRE(lda % 8 == 0 && lda >= round_up(C, 8), "head_fwd: bad ld");
   const int64_t npix = (int64_t)N * HW;
-  const int grid = stream_grid(npix, 256);
-  const size_t lds = (size_t)Co * round_up(C, 8) * sizeof(float);
-  MAU_REQUIRE(lds <= 48 * 1024, "head_fwd: C too large");
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(head_fwd_kernel<T>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const T*)a, lda, w, b, out, tanh0, HW, C, Co, npix));
+  const int grid = stream_grid(npix * 8, 256);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(head_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, w, b, out, tanh0, HW, C, Co, npix));
   return check_launch("head_fwd_kernel");
 }
 

@@ -32,7 +32,7 @@ for name, cin, cout, h in layers:
     dy = torch.randn(N, H, W, F_.pad8(cout), device="cuda").to(dt)
     w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
     bias = torch.zeros(cout, device="cuda")
-    wf = F_.PACK_CACHE.get(w, code, "f"); wd = F_.PACK_CACHE.get(w, code, "d")
+    wf, wd = F_.pack_conv_weights(w, code, forward=True, dgrad=True)
     y = torch.empty(N, H, W, F_.pad8(cout), device="cuda", dtype=dt)
     dx = torch.empty(N, H, W, F_.pad8(cin), device="cuda", dtype=dt)
     tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W); cpad = (cout + 63) // 64 * 64

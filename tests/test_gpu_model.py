@@ -205,3 +205,37 @@ def test_graphed_inference_matches_eager(mau, model_type):
     assert torch.equal(sess(*b), ref_b)
     with pytest.raises(ValueError):
         sess(torch.zeros(2, 23, 96, 96, device="cuda"), b[1], b[2])
+
+
+@pytest.mark.parametrize("opt_kw", [dict(fused=True), dict(foreach=True)])
+def test_multi_step_training_tracks_oracle(mau, opt_kw):
+    """Several optimizer steps: the weights used by step k must be the weights written by step k-1.
+    (Regression: fused AdamW updates parameters in place WITHOUT bumping Tensor._version, which once made a
+    version-keyed packed-weight cache serve stale weights from the second step on.)"""
+    flags = dict(temporal_embeddings=False, metadata_embeddings=True)
+    torch.manual_seed(21)
+    net = mau.UrbanPredictor("unet", 6, 10, 8, 4, 8, 12, 2, base_filters=8, **flags)
+    sd = R.clone_state({k: v.clone() for k, v in net.state_dict().items()}, requires_grad=True)
+    ref_opt = torch.optim.AdamW([sd[k] for k in sd if R.is_param(k)], lr=3e-3, weight_decay=1e-3)
+    net = net.cuda().set_precision("fp32").train()
+    opt = torch.optim.AdamW(net.parameters(), lr=3e-3, weight_decay=1e-3, **opt_kw)
+    g = torch.Generator().manual_seed(22)
+    ref_losses, losses = [], []
+    for step in range(5):
+        x, ts, md, tgt = torch.randn(2, 6, 32, 32, generator=g), torch.randn(2, 10, generator=g), torch.randn(2, 4, generator=g), torch.randn(2, 2, 32, 32, generator=g)
+        loss_ref, _, _ = R.train_step("unet", sd, ref_opt, x, ts, md, tgt, **flags)
+        out = net(x.cuda(), ts.cuda(), md.cuda())
+        loss = mau.compute_loss_mse(out, tgt.cuda())["total"]
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        ref_losses.append(float(loss_ref))
+        losses.append(float(loss))
+    for k, (a, b) in enumerate(zip(losses, ref_losses)):
+        assert abs(a - b) < 2e-3 * abs(b), (k, losses, ref_losses)
+    # with stale weights the eval output after training would equal the initial model's: check it moved with the oracle
+    net.eval()
+    with torch.no_grad():
+        out_eval = net(x.cuda(), ts.cuda(), md.cuda()).cpu()
+        ref_eval = R.forward("unet", {k: v.detach() for k, v in sd.items()}, x, ts, md, False, **flags)
+    assert rel_err(out_eval, ref_eval) < 2e-2

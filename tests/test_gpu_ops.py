@@ -76,7 +76,7 @@ def test_conv3x3_exact_integers(mau, dt, shape):
     code = F_.dtype_code(dt)
     a = to_act(mau, x, dt)
     wd = dev(w)
-    wf = F_.PACK_CACHE.get(wd, code, "f")
+    wf = F_.pack_conv_weights(wd, code)[0]
     y = torch.empty((N, H, W, F_.pad8(Cout)), dtype=dt, device="cuda")
     tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W)
     cpad = (Cout + 63) // 64 * 64
@@ -114,7 +114,7 @@ def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
     st = torch.cuda.current_stream().cuda_stream
     xa, dya = to_act(mau, x.detach(), dt), to_act(mau, dy, dt)
     wdv = dev(w.detach())
-    wdp = F_.PACK_CACHE.get(wdv, code, "d")
+    wdp = F_.pack_conv_weights(wdv, code, forward=False, dgrad=True)[1]
     dx = torch.empty((N, H, W, F_.pad8(Cin)), dtype=dt, device="cuda")
     call("mau_conv3x3_fwd", dya.t.data_ptr(), dya.t.shape[-1], Cout, None, None, 0, wdp.data_ptr(), None, None, None, dx.data_ptr(),
          dx.shape[-1], Cin, None, code, N, H, W, st)
