@@ -197,6 +197,14 @@ int mau_mse_blocks(int64_t n);
 int mau_mse_fwd_bwd(const float* out, const float* tgt, double* partial, float* loss, float* dout, int64_t n,
                     mau_stream_t stream);
 
+/* ---- L1 + gradient (finite-difference) losses (src/utils/losses.py:5-25 gradient_loss, :68 F.l1_loss) ---- */
+/* out/tgt (B,C,H,W) fp32.  terms[0..2] = { mean|out-tgt|, mean| |dy out|-|dy tgt| |, mean| |dx out|-|dx tgt| | }
+ * (gradient_loss = terms[1] + terms[2]);  dout (optional) = d/d out of  w_l1*terms[0] + w_grad*(terms[1]+terms[2]).
+ * partial: fp64 workspace of 3*mau_l1_gradient_blocks(n) elements, n = B*C*H*W. */
+int mau_l1_gradient_blocks(int64_t n);
+int mau_l1_gradient_loss(const float* out, const float* tgt, double* partial, float* terms, float* dout, float w_l1,
+                         float w_grad, int B, int C, int H, int W, mau_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,8 +6,10 @@ contains hyphens).  Importing loads ``libmau_hip.so`` and fails loudly when it i
 from . import _lib                      # noqa: F401  (raises if the HIP library is absent)
 from .model import (MetadataEncoder, TemporalEncoder, UrbanPredictor, UrbanPredictor_unet,  # noqa: F401
                     UrbanPredictor_unetpp, VGGBlock)
-from .losses import compute_loss_mse   # noqa: F401
+from .losses import (compute_loss_l1_grad_ssim, compute_loss_mse, compute_loss_mse_gradient,   # noqa: F401
+                     gradient_loss)
 from .inference import GraphedInference  # noqa: F401
 
 __all__ = ["UrbanPredictor", "UrbanPredictor_unet", "UrbanPredictor_unetpp", "VGGBlock", "MetadataEncoder",
-           "TemporalEncoder", "compute_loss_mse", "GraphedInference"]
+           "TemporalEncoder", "compute_loss_mse", "compute_loss_mse_gradient", "compute_loss_l1_grad_ssim", "gradient_loss",
+           "GraphedInference"]

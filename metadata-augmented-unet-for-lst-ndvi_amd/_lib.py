@@ -64,6 +64,8 @@ PROTOTYPES = {
     "mau_meta_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mau_meta_mlp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mau_mse_blocks": (_i, [_i64]),
+    "mau_l1_gradient_blocks": (_i, [_i64]),
+    "mau_l1_gradient_loss": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i, _i, _i, _p]),
     "mau_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
 }
 

@@ -259,6 +259,76 @@ __global__ void mse_final_kernel(const double* __restrict__ partial, int nblocks
   if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) * inv_n);
 }
 
+// ---- L1 and gradient (finite-difference) losses of src/utils/losses.py:5-25,68 on (B,C,H,W) fp32 ------------
+// One thread per element.  partial[block] = {sum |o-t|, sum | |dy o| - |dy t| |, sum | |dx o| - |dx t| |} (fp64);
+// dout (optional) = k_l1 * sign(o-t) + k_gy * d/do(sum_y) + k_gx * d/do(sum_x), where the coefficients fold the
+// 1/count means and the lambda weights.  Each element sees the two vertical and the two horizontal differences
+// it takes part in (gather form: no atomics).
+__device__ __forceinline__ float sgnf(float v) { return (v > 0.f) - (v < 0.f); }
+
+__global__ __launch_bounds__(256) void l1_gradient_loss_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                               double* __restrict__ partial, float* __restrict__ dout, int H,
+                                                               int W, int64_t n, float k_l1, float k_gy, float k_gx) {
+  __shared__ double red[3][4];
+  double s_l1 = 0.0, s_gy = 0.0, s_gx = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float o = out[i], t = tgt[i];
+    float g = k_l1 * sgnf(o - t);
+    s_l1 += fabsf(o - t);
+    if (y + 1 < H) {            // difference (y+1) - y : this element is the minuend's partner "p[y]"
+      const float a = out[i + W] - o, b = tgt[i + W] - t;
+      const float d = fabsf(a) - fabsf(b);
+      s_gy += fabsf(d);
+      g -= k_gy * sgnf(d) * sgnf(a);
+    }
+    if (y > 0) {                // difference y - (y-1) : this element is "p[y+1]" of the row above
+      const float a = o - out[i - W], b = t - tgt[i - W];
+      g += k_gy * sgnf(fabsf(a) - fabsf(b)) * sgnf(a);
+    }
+    if (x + 1 < W) {
+      const float a = out[i + 1] - o, b = tgt[i + 1] - t;
+      const float d = fabsf(a) - fabsf(b);
+      s_gx += fabsf(d);
+      g -= k_gx * sgnf(d) * sgnf(a);
+    }
+    if (x > 0) {
+      const float a = o - out[i - 1], b = t - tgt[i - 1];
+      g += k_gx * sgnf(fabsf(a) - fabsf(b)) * sgnf(a);
+    }
+    if (dout) dout[i] = g;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s_l1 += __shfl_xor(s_l1, o);
+    s_gy += __shfl_xor(s_gy, o);
+    s_gx += __shfl_xor(s_gx, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s_l1;
+    red[1][threadIdx.x >> 6] = s_gy;
+    red[2][threadIdx.x >> 6] = s_gx;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) partial[(size_t)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+// terms[0..2] = {mean |o-t|, mean_y term, mean_x term}
+__global__ void l1_gradient_final_kernel(const double* __restrict__ partial, int nblocks, double inv_n, double inv_ny, double inv_nx,
+                                         float* __restrict__ terms) {
+  __shared__ double red[3][4];
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x)
+    for (int k = 0; k < 3; ++k) s[k] += partial[(size_t)i * 3 + k];
+  for (int k = 0; k < 3; ++k) {
+    for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const double v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    terms[threadIdx.x] = (float)(v * (threadIdx.x == 0 ? inv_n : threadIdx.x == 1 ? inv_ny : inv_nx));
+  }
+}
+
 }  // namespace mau
 
 using namespace mau;
@@ -318,6 +388,21 @@ int mau_mse_fwd_bwd(const float* out, const float* tgt, double* partial, float* 
   MAU_LAUNCH(mse_kernel, dim3(blocks), dim3(256), 0, st, out, tgt, partial, dout, n, 2.0f / (float)n);
   MAU_LAUNCH(mse_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks, 1.0 / (double)n, loss);
   return check_launch("mse_kernel");
+}
+
+int mau_l1_gradient_blocks(int64_t n) { return stream_grid(n, 256); }
+
+int mau_l1_gradient_loss(const float* out, const float* tgt, double* partial, float* terms, float* dout, float w_l1,
+                         float w_grad, int B, int C, int H, int W, mau_stream_t stream) {
+  MAU_REQUIRE(out && tgt && partial && terms && B > 0 && C > 0 && H > 0 && W > 0, "l1_gradient_loss: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = (int64_t)B * C * H * W, ny = (int64_t)B * C * (H - 1) * W, nx = (int64_t)B * C * H * (W - 1);
+  const int blocks = mau_l1_gradient_blocks(n);
+  const float k_l1 = w_l1 / (float)n, k_gy = ny > 0 ? w_grad / (float)ny : 0.f, k_gx = nx > 0 ? w_grad / (float)nx : 0.f;
+  MAU_LAUNCH(l1_gradient_loss_kernel, dim3(blocks), dim3(256), 0, st, out, tgt, partial, dout, H, W, n, k_l1, k_gy, k_gx);
+  MAU_LAUNCH(l1_gradient_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks, 1.0 / (double)n, ny > 0 ? 1.0 / (double)ny : 0.0,
+             nx > 0 ? 1.0 / (double)nx : 0.0, terms);
+  return check_launch("l1_gradient_loss_kernel");
 }
 
 }  // extern "C"

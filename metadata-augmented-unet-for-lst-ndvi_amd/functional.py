@@ -569,3 +569,39 @@ class MSELoss(torch.autograd.Function):
         d = ctx.dout
         ctx.dout = None
         return d * g, None
+
+
+class L1GradientLoss(torch.autograd.Function):
+    """(mean|o-t|, gradient_loss(o,t)) of src/utils/losses.py:5-25,68 and, for backward, the gradient of
+    ``w_l1 * l1 + w_grad * gradient_loss`` produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, out, tgt, w_l1: float, w_grad: float):
+        _require_cuda(out, "gradient_loss")
+        out = out.contiguous().float()
+        tgt = tgt.contiguous().float()
+        B, Cc, H, W = out.shape
+        n = out.numel()
+        partial = torch.empty(3 * lib.mau_l1_gradient_blocks(n), dtype=torch.float64, device=out.device)
+        terms = torch.empty(3, dtype=torch.float32, device=out.device)
+        dout = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        call("mau_l1_gradient_loss", out.data_ptr(), tgt.data_ptr(), partial.data_ptr(), terms.data_ptr(),
+             dout.data_ptr() if dout is not None else None, float(w_l1), float(w_grad), B, Cc, H, W, _stream())
+        ctx.dout = dout
+        ctx.w = (float(w_l1), float(w_grad))
+        l1 = terms[0]
+        grad_loss = terms[1] + terms[2]
+        return l1, grad_loss
+
+    @staticmethod
+    def backward(ctx, g_l1, g_grad):
+        # dout already holds d(w_l1*l1 + w_grad*grad)/dout; callers combine the two outputs with exactly these weights
+        d = ctx.dout
+        ctx.dout = None
+        w_l1, w_grad = ctx.w
+        scale = None
+        if w_l1 != 0.0:
+            scale = g_l1 / w_l1
+        elif w_grad != 0.0:
+            scale = g_grad / w_grad
+        return (d * scale if scale is not None else torch.zeros_like(d)), None, None, None

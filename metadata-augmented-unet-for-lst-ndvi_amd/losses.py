@@ -1,8 +1,68 @@
-"""Mirror of the reference's MSE criterion (src/utils/losses.py:27-39) on the HIP path."""
-from .functional import MSELoss
+"""Mirror of the reference's criteria (src/utils/losses.py) on the HIP path.
+
+* ``compute_loss_mse``            :27-39   F.mse_loss                                   -> HIP kernel
+* ``gradient_loss``               :5-25    mean | |dy pred| - |dy tgt| | + same in x    -> HIP kernel
+* ``compute_loss_mse_gradient``   :41-57   mse + 0.1 * gradient
+* ``compute_loss_l1_grad_ssim``   :59-99   l1 + 0.1 * gradient + 0.5 * (1 - ssim)       (the yaml default, conf/config.yaml:42)
+
+In the reference the SSIM values pass through ``torch.Tensor(ssim_vals)`` (:96), which detaches them: the SSIM
+term changes the reported number, never the gradient.  ``piq`` (the SSIM provider) is not available in the
+build environment, so the SSIM VALUE below follows piq's published default algorithm (11x11 Gaussian, sigma
+1.5, k1 0.01, k2 0.03, average-pool downsampling by max(1, round(min(H, W)/256))) with plain torch ops and is
+**parity-unpinned**; everything that carries gradient is pinned by fixture ``g9_losses.npz``.
+"""
+import torch
+import torch.nn.functional as F
+
+from .functional import L1GradientLoss, MSELoss
 
 
 def compute_loss_mse(outputs, targets):
     """Same return contract as the reference: {'total': loss, 'mse': loss} (src/utils/losses.py:34-39)."""
     mse = MSELoss.apply(outputs, targets)
     return {"total": mse, "mse": mse}
+
+
+def gradient_loss(pred, target):
+    """src/utils/losses.py:5-25."""
+    _, g = L1GradientLoss.apply(pred, target, 0.0, 1.0)
+    return {"gradient": g}
+
+
+def compute_loss_mse_gradient(outputs, targets, lambda_grad=0.1):
+    """src/utils/losses.py:41-57."""
+    mse = MSELoss.apply(outputs, targets)
+    _, g = L1GradientLoss.apply(outputs, targets, 0.0, lambda_grad)
+    return {"total": mse + lambda_grad * g, "mse": mse, "gradient": g}
+
+
+def _ssim_value(x, y, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
+    """Per-image SSIM averaged over channels (piq.ssim defaults, reduction='none'); reporting only, no gradient."""
+    with torch.no_grad():
+        x, y = x / data_range, y / data_range
+        f = max(1, round(min(x.shape[-2:]) / 256))
+        if f > 1:
+            x, y = F.avg_pool2d(x, f), F.avg_pool2d(y, f)
+        c = torch.arange(kernel_size, dtype=x.dtype, device=x.device) - (kernel_size - 1) / 2.0
+        g1 = torch.exp(-(c ** 2) / (2 * sigma ** 2))
+        k = (g1[:, None] * g1[None, :])
+        k = (k / k.sum())[None, None].repeat(x.shape[1], 1, 1, 1)
+        C = x.shape[1]
+        mu_x, mu_y = F.conv2d(x, k, groups=C), F.conv2d(y, k, groups=C)
+        sxx = F.conv2d(x * x, k, groups=C) - mu_x ** 2
+        syy = F.conv2d(y * y, k, groups=C) - mu_y ** 2
+        sxy = F.conv2d(x * y, k, groups=C) - mu_x * mu_y
+        c1, c2 = k1 ** 2, k2 ** 2
+        cs = (2 * sxy + c2) / (sxx + syy + c2)
+        ss = (2 * mu_x * mu_y + c1) / (mu_x ** 2 + mu_y ** 2 + c1) * cs
+        return ss.mean(dim=(-1, -2)).mean(dim=1)
+
+
+def compute_loss_l1_grad_ssim(outputs, targets, lambda_grad=0.1, lambda_ssim=0.5):
+    """src/utils/losses.py:59-99 (same dict keys).  Gradient = d(l1 + lambda_grad*gradient); SSIM is value-only."""
+    l1, g = L1GradientLoss.apply(outputs, targets, 1.0, lambda_grad)
+    o = torch.stack([(outputs[:, 0] + 1.0) / 2.0, torch.clamp(outputs[:, 1], 0.0, 1.0)], dim=1).detach()   # :72-84
+    t = torch.stack([(targets[:, 0] + 1.0) / 2.0, torch.clamp(targets[:, 1], 0.0, 1.0)], dim=1).detach()
+    ssim_loss = 1 - _ssim_value(o, t, data_range=1.0).mean()                                                # :88-89
+    total = l1 + lambda_grad * g + lambda_ssim * ssim_loss
+    return {"total": total, "pixel": l1, "gradient": g, "ssim": ssim_loss}

@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 import typer
 
-from . import compute_loss_mse
+from . import compute_loss_l1_grad_ssim, compute_loss_mse, compute_loss_mse_gradient
 from .checkpoint import build_hyperparameters, save_checkpoint
 from .config import CONFIG
 from .dist import GradSync, init_process_group_from_env
@@ -70,6 +70,10 @@ def main(device: str = "", wandblog: bool = False, n_trials: int = 1, force_stud
         raise NotImplementedError(f"Optimizer {cfg.optimizer} not implemented.")
     if cfg.loss == "mse":                                                                     # src/train.py:218-225
         criterion = compute_loss_mse
+    elif cfg.loss == "mse-gradient":
+        criterion = compute_loss_mse_gradient
+    elif cfg.loss == "l1-gradient-ssim":
+        criterion = compute_loss_l1_grad_ssim
     else:
         raise NotImplementedError(f"Loss {cfg.loss} not implemented.")
     sync = None

@@ -268,6 +268,30 @@ def loss_mse(outputs, targets):
     return {"total": mse, "mse": mse}
 
 
+def gradient_loss(pred, target):
+    """gradient_loss, src/utils/losses.py:5-25: mean | |dy pred| - |dy target| | + the same along x."""
+    dy_p = torch.abs(pred[:, :, 1:, :] - pred[:, :, :-1, :])
+    dx_p = torch.abs(pred[:, :, :, 1:] - pred[:, :, :, :-1])
+    dy_t = torch.abs(target[:, :, 1:, :] - target[:, :, :-1, :])
+    dx_t = torch.abs(target[:, :, :, 1:] - target[:, :, :, :-1])
+    return {"gradient": torch.mean(torch.abs(dy_p - dy_t)) + torch.mean(torch.abs(dx_p - dx_t))}
+
+
+def loss_mse_gradient(outputs, targets, lambda_grad: float = 0.1):
+    """compute_loss_mse_gradient, src/utils/losses.py:41-57."""
+    mse = loss_mse(outputs, targets)["mse"]
+    g = gradient_loss(outputs, targets)["gradient"]
+    return {"total": mse + lambda_grad * g, "mse": mse, "gradient": g}
+
+
+def loss_l1_gradient(outputs, targets, lambda_grad: float = 0.1):
+    """Differentiable part of compute_loss_l1_grad_ssim, src/utils/losses.py:59-99: the SSIM term is wrapped in
+    ``torch.Tensor(...)`` there (:96), i.e. detached -- it shifts the reported value, never the gradient."""
+    l1 = F.l1_loss(outputs, targets)
+    g = gradient_loss(outputs, targets)["gradient"]
+    return {"pixel": l1, "gradient": g, "l1_gradient": l1 + lambda_grad * g}
+
+
 def train_step(model_type: str, sd: State, optimizer, maps, temp_series, metadata, targets, **flags):
     """Inner step of src/train.py:243-256 (MSE criterion, no clipping): fwd, loss, bwd, step, zero_grad.
 

@@ -246,6 +246,32 @@ def g8_syncbn(ref):
         **{f"grad/{k}": p.grad for k, p in blk.named_parameters()})
 
 
+def g9_losses():
+    """src/utils/losses.py: piq (SSIM) is not installed; it is stubbed so the module imports, and only the
+    functions that never reach it are exercised (gradient_loss :5-25, compute_loss_mse :27-39,
+    compute_loss_mse_gradient :41-57; L1 = F.l1_loss :68)."""
+    stub = types.ModuleType("piq")
+    stub.ssim = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("piq.ssim is not available in this container"))
+    sys.modules.setdefault("piq", stub)
+    import src.utils.losses as L
+    g = torch.Generator().manual_seed(90)
+    out = {}
+    for tag, shape in {"a": (2, 2, 17, 13), "b": (3, 2, 32, 32), "c": (1, 2, 250, 250)}.items():
+        o = torch.randn(shape, generator=g, requires_grad=True)
+        t = torch.randn(shape, generator=g)
+        d = L.compute_loss_mse_gradient(o, t)
+        d["total"].backward()
+        out.update({f"{tag}/out": o, f"{tag}/tgt": t, f"{tag}/mse_gradient_total": d["total"].detach().reshape(1),
+                    f"{tag}/mse": d["mse"].detach().reshape(1), f"{tag}/gradient": d["gradient"].detach().reshape(1),
+                    f"{tag}/d_mse_gradient": o.grad.clone()})
+        o.grad = None
+        l1 = F.l1_loss(o, t)
+        gl = L.gradient_loss(o, t)["gradient"]
+        (l1 + 0.1 * gl).backward()                 # the differentiable part of compute_loss_l1_grad_ssim (:68-71,99)
+        out.update({f"{tag}/l1": l1.detach().reshape(1), f"{tag}/d_l1_gradient": o.grad.clone()})
+    npz("g9_losses.npz", **out)
+
+
 def main():
     ref = import_reference()
     torch.set_num_threads(8)
@@ -263,6 +289,7 @@ def main():
     full_model_case(ref, "g6_unetpp_odd.npz", "unet++", 1, 7, 8, 34, 34, 5, 4, {}, seed=61)
     g7_full_summary(ref)
     g8_syncbn(ref)
+    g9_losses()
 
 
 if __name__ == "__main__":

@@ -303,3 +303,25 @@ def test_mse_loss(mau):
         got["total"].backward()
         assert abs(float(got["total"]) - float(ref)) < 1e-6 * abs(float(ref))
         assert rel_err(oc.grad.cpu(), o.grad) < 1e-6
+
+
+def test_g9_loss_suite(mau):
+    """HIP gradient / L1 losses and their gradients against the reference fixture (src/utils/losses.py)."""
+    d = load_npz("g9_losses.npz")
+    for tag in ("a", "b", "c"):
+        tg = dev(t(d[f"{tag}/tgt"]))
+        o = dev(t(d[f"{tag}/out"])).requires_grad_(True)
+        r = mau.compute_loss_mse_gradient(o, tg)
+        assert set(r) == {"total", "mse", "gradient"}
+        r["total"].backward()
+        assert abs(float(r["total"]) - float(d[f"{tag}/mse_gradient_total"][0])) < 1e-5 * abs(float(d[f"{tag}/mse_gradient_total"][0]))
+        assert abs(float(r["gradient"]) - float(d[f"{tag}/gradient"][0])) < 1e-5 * float(d[f"{tag}/gradient"][0])
+        assert rel_err(o.grad.cpu(), t(d[f"{tag}/d_mse_gradient"])) < 1e-5
+        o2 = dev(t(d[f"{tag}/out"])).requires_grad_(True)
+        r2 = mau.compute_loss_l1_grad_ssim(o2, tg)
+        assert set(r2) == {"total", "pixel", "gradient", "ssim"}
+        r2["total"].backward()
+        assert abs(float(r2["pixel"]) - float(d[f"{tag}/l1"][0])) < 1e-5 * float(d[f"{tag}/l1"][0])
+        assert rel_err(o2.grad.cpu(), t(d[f"{tag}/d_l1_gradient"])) < 1e-5          # SSIM carries no gradient (losses.py:96)
+        assert 0.0 <= float(r2["ssim"]) <= 2.0
+        assert float(mau.gradient_loss(o2.detach(), tg)["gradient"]) == pytest.approx(float(d[f"{tag}/gradient"][0]), rel=1e-5)

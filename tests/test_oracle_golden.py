@@ -182,3 +182,21 @@ def test_g8_syncbn_pooled_equals_single_device():
         pooled = torch.cat(R.bn_train_pooled(parts, sd0["bn1.weight"], sd0["bn1.bias"]), dim=0)
         ref = torch.nn.functional.batch_norm(y1, None, None, sd0["bn1.weight"], sd0["bn1.bias"], True, 0.1, 1e-5)
         assert rel_err(pooled, ref) < 1e-6
+
+
+def test_g9_losses_oracle():
+    """gradient_loss / compute_loss_mse_gradient / the differentiable part of compute_loss_l1_grad_ssim."""
+    d = load_npz("g9_losses.npz")
+    for tag in ("a", "b", "c"):
+        o = t(d[f"{tag}/out"]).requires_grad_(True)
+        tg = t(d[f"{tag}/tgt"])
+        r = R.loss_mse_gradient(o, tg)
+        r["total"].backward()
+        assert torch.equal(r["total"].detach().reshape(1), t(d[f"{tag}/mse_gradient_total"]))
+        assert torch.equal(r["gradient"].detach().reshape(1), t(d[f"{tag}/gradient"]))
+        assert torch.equal(o.grad, t(d[f"{tag}/d_mse_gradient"]))
+        o.grad = None
+        r2 = R.loss_l1_gradient(o, tg)
+        r2["l1_gradient"].backward()
+        assert torch.equal(r2["pixel"].detach().reshape(1), t(d[f"{tag}/l1"]))
+        assert torch.equal(o.grad, t(d[f"{tag}/d_l1_gradient"]))
