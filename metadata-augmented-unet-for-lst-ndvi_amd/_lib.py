@@ -32,7 +32,7 @@ PROTOTYPES = {
     "mau_conv3x3_kc": (_i, [_i]),
     "mau_conv3x3_packed_elems": (_sz, [_i, _i, _i]),
     "mau_conv3x3_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _p]),
-    "mau_conv3x3_num_pixel_tiles": (_i, [_i, _i, _i, _i]),
+    "mau_conv3x3_num_pixel_tiles": (_i, [_i, _i, _i, _i, _i]),
     "mau_conv3x3_fwd": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),
     "mau_conv3x3_wgrad_acc_elems": (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -449,8 +449,8 @@ int mau_conv3x3_pack_weights(const float* w, void* wf, void* wd, int dtype, int 
   return check_launch("pack_weights_kernel");
 }
 
-int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W) {
-  return dtype == MAU_BF16 ? conv_bf16_v2_num_pixel_tiles(N, H, W) : N * ceil_div(H, TH) * ceil_div(W, TW);
+int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout) {
+  return dtype == MAU_BF16 ? conv_bf16_v2_num_pixel_tiles(N, H, W, Cout) : N * ceil_div(H, TH) * ceil_div(W, TW);
 }
 
 __global__ void cast_f32_to_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int n) {

@@ -27,26 +27,27 @@
 namespace mau {
 
 namespace v2 {
-constexpr int TS = 16;                 // spatial tile side
-constexpr int HS = TS + 2;             // halo side
-constexpr int HPIX = HS * HS;          // 324
+constexpr int TW = 16;                 // tile width (pixels); the tile height TH depends on the variant
+constexpr int HS = TW + 2;             // halo row pitch (pixels)
 constexpr int KC = 16;                 // channels per stage
 constexpr int ROWB = KC * 2;           // 32 bytes per LDS row (pixel or weight row)
-constexpr int HALO_Q = (HPIX * 2 + 63) / 64;   // 11 wave-DMAs (1 KiB each) for the halo tile
-constexpr int HALO_BYTES = HALO_Q * 1024;
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef __attribute__((address_space(1))) const void* glb_ptr;
 
-__device__ __forceinline__ int swz_off(int row, int half) { return row * ROWB + 16 * (half ^ ((row >> 3) & 1)); }
-
 // ds_read_b128 is serviced in the 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (same for
 // lanes 32-63).  The assignment "MFMA row/column index i -> tile row" is ours to choose: perm32 sends
 // the first group to rows 0..15 and the second to rows 16..31, so every group reads 16 CONSECUTIVE
-// 32-byte rows, which the (row>>3)&1 chunk swizzle spreads over the 16 distinct 16-byte bank slots.
+// 32-byte rows; the chunk swizzles below then spread such a run over the 16 distinct 16-byte bank slots.
 __device__ __forceinline__ int perm32(int i) {
   return i < 4 ? i : i < 12 ? i + 12 : i < 16 ? i - 8 : i < 20 ? i + 8 : i < 28 ? i - 12 : i;
 }
+// weight rows: swizzle keyed on the row index (rows come in aligned runs of 16)
+__device__ __forceinline__ int w_off(int row, int half) { return row * ROWB + 16 * (half ^ ((row >> 3) & 1)); }
+// halo pixels: swizzle keyed on the halo COLUMN hx (0..17).  A 16-pixel run hx..hx+15 of one halo row holds
+// every residue of hp mod 8 twice, and the two always differ in bit 3 of hx -> 16 distinct slots; and because
+// the key ignores the halo row, a tap's (dy, mt) row shift is a pure immediate offset of the read address.
+__device__ __forceinline__ int halo_swz(int hx) { return (hx >> 3) & 1; }
 
 // counted wait on the vector-memory counter (LDS-DMA included); N must be a compile-time constant
 template <int N>
@@ -64,20 +65,40 @@ constexpr int EPI_PLAIN = 0;   // y = conv (+bias)                      : data g
 constexpr int EPI_STATS = 1;   // + BatchNorm partial sums              : training forward
 constexpr int EPI_POST = 2;    // y = relu(scale*(conv+bias) + shift)   : inference (eval-mode BN + ReLU folded in)
 
-template <int BN, int EPI>
-__global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
-  constexpr int NW = BN / 16;                         // waves per workgroup
-  constexpr int W_Q = 9 * BN * 2 / 64;                // wave-DMAs for the weight slab
-  constexpr int TOT_Q = HALO_Q + W_Q;
-  constexpr int STAGE = HALO_BYTES + W_Q * 1024;      // bytes per LDS stage
-  constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;     // DMAs per wave per stage
-  constexpr int RED_OFF = 2 * STAGE;                  // [4 wm][2][BN] floats for the BatchNorm partials
+// Geometry of a variant: NW waves = WM (pixel direction) x WN (= BN/64 channel direction); a wave owns
+// MT x 32 pixels (MT x 2 tile rows of 16) x 64 channels = MT x 2 accumulator tiles of 32x32.
+//   <128, 2, 8>: 16x16 px tile     <128, 4, 8>: 32x16 px tile (128 accumulator registers per lane)
+//   < 64, 2, 4>: 16x16             < 64, 2, 8>: 32x16            < 64, 4, 8>: 64x16
+// Larger tiles move fewer LDS-DMA bytes per MFMA (weights are shared by more pixels, the halo by more
+// channels): the ablation in DESIGN.md prices each DMA stream at ~12 % of the kernel time.
+template <int BN, int MT, int NW>
+struct Geo {
+  static constexpr int WN = BN / 64, WM = NW / WN;
+  static constexpr int TH = WM * MT * 2;                       // tile rows
+  static constexpr int HPIX = (TH + 2) * HS;                   // halo pixels
+  static constexpr int HALO_Q = (HPIX * 2 + 63) / 64;          // wave-DMAs (1 KiB each) for the halo tile
+  static constexpr int HALO_BYTES = HALO_Q * 1024;
+  static constexpr int W_Q = 9 * BN * 2 / 64;                  // wave-DMAs for the weight slab
+  static constexpr int TOT_Q = HALO_Q + W_Q;
+  static constexpr int STAGE = HALO_BYTES + W_Q * 1024;        // bytes per LDS stage
+  static constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;
+  static constexpr int RED_OFF = 2 * STAGE;
+  static constexpr size_t LDS = 2 * (size_t)STAGE + (size_t)WM * 2 * BN * sizeof(float);
+  static_assert(NW % WN == 0 && (size_t)NW * 32 * 64 * 2 <= STAGE, "epilogue staging must fit one stage buffer");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <int BN, int MT, int NW, int EPI>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
+  using G = Geo<BN, MT, NW>;
+  constexpr int WN = G::WN, WM = G::WM, TH = G::TH, HPIX = G::HPIX, HALO_Q = G::HALO_Q, HALO_BYTES = G::HALO_BYTES;
+  constexpr int TOT_Q = G::TOT_Q, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE + red
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;            // 4 (pixel rows) x BN/64 (channels)
+  const int wm = wave % WM, wn = wave / WM;
   const int i32 = perm32(lane & 31), h = lane >> 5;   // tile row (pixel / channel) this lane's operands come from
 
   const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(p.x);
@@ -96,8 +117,8 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
     t /= p.tilesX;
     const int tyi = t % p.tilesY;
     it.n = t / p.tilesY;
-    it.ty0 = tyi * TS;
-    it.tx0 = txi * TS;
+    it.ty0 = tyi * TH;
+    it.tx0 = txi * TW;
     return true;
   };
   auto next_valid = [&](int I, Item& it) -> int {
@@ -117,7 +138,7 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
     if (q < HALO_Q) {
       const int slot = q * 64 + lane;
       const int hp = slot >> 1, ph = slot & 1;
-      slot_c[j] = 8 * (ph ^ ((hp >> 3) & 1));
+      slot_c[j] = 8 * (ph ^ halo_swz(hp % HS));
       slot_hp[j] = hp < HPIX ? hp : -1;
     } else if (q < TOT_Q) {
       const int slot = (q - HALO_Q) * 64 + lane;
@@ -171,17 +192,15 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
     }
   };
 
-  // ---- per-lane LDS read offsets (constant) ----
-  int aoff[2][9];
+  // ---- per-lane LDS read addresses: three bases (one per dx) + immediates for (mt, dy); two for the weights ----
+  int abase[3];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int hp = (wm * 4 + mt * 2 + (i32 >> 4) + tap / 3) * HS + (i32 & 15) + tap % 3;
-      aoff[mt][tap] = swz_off(hp, h);
-    }
-  const int boff0 = HALO_BYTES + swz_off(wn * 64 + i32, h);          // (tap*BN is a multiple of 16 rows: swizzle unchanged)
-  const int boff1 = HALO_BYTES + swz_off(wn * 64 + 32 + i32, h);
+  for (int dx = 0; dx < 3; ++dx) {
+    const int hx = (i32 & 15) + dx;
+    abase[dx] = ((wm * MT * 2 + (i32 >> 4)) * HS + hx) * ROWB + 16 * (h ^ halo_swz(hx));
+  }
+  const int boff0 = HALO_BYTES + w_off(wn * 64 + i32, h);          // (tap*BN is a multiple of 16 rows: swizzle unchanged)
+  const int boff1 = HALO_BYTES + w_off(wn * 64 + 32 + i32, h);
 
   // accumulator register r of lane half h holds MFMA row (r&3) + 8*(r>>2) + 4*h, i.e. tile row
   // perm32(that) = rowbase[r>>2] + (r&3): four per-lane bases + immediates address the whole epilogue
@@ -196,13 +215,13 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
   issue(0, 0);
   int stage = 0;
   bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
-  float* red = reinterpret_cast<float*>(smem + RED_OFF);
+  float* red = reinterpret_cast<float*>(smem + G::RED_OFF);
 
   while (true) {
     const int In = next_valid(I + gridDim.x, nxt);
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -221,37 +240,18 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
         issue(stage ^ 1, 0);
       }
       const unsigned char* sb = smem + stage * STAGE;
-      bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sb + aoff[0][0]);
-      bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sb + aoff[1][0]);
-      bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + boff0);
-      bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + boff1);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        bf16x8 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-        if (tap < 8) {
-          na0 = *reinterpret_cast<const bf16x8*>(sb + aoff[0][tap + 1]);
-          na1 = *reinterpret_cast<const bf16x8*>(sb + aoff[1][tap + 1]);
-          nb0 = *reinterpret_cast<const bf16x8*>(sb + boff0 + (tap + 1) * BN * ROWB);
-          nb1 = *reinterpret_cast<const bf16x8*>(sb + boff1 + (tap + 1) * BN * ROWB);
-        }
-        acc[0][0] = mfma32(a0, b0, acc[0][0]);
-        acc[0][1] = mfma32(a0, b1, acc[0][1]);
-        acc[1][0] = mfma32(a1, b0, acc[1][0]);
-        acc[1][1] = mfma32(a1, b1, acc[1][1]);
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-      }
-      // pin the interleave (LLVM SchedGroupMask: 0x100 = DS read, 0x008 = MFMA): 4 reads of tap 0, then
-      // per tap {1 MFMA of tap t, 1 read of tap t+1} x 4; the last tap is MFMA only.
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        const int dy = tap / 3, dx = tap % 3;
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + boff0 + tap * BN * ROWB);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + boff1 + tap * BN * ROWB);
 #pragma unroll
-      for (int tap = 0; tap < 8; ++tap) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + abase[dx] + (mt * 2 + dy) * HS * ROWB);
+          acc[mt][0] = mfma32(a, b0, acc[mt][0]);
+          acc[mt][1] = mfma32(a, b1, acc[mt][1]);
         }
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       stage ^= 1;
     }
 
@@ -271,12 +271,13 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
     }
     const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
     // interior tiles (the common case) take the mask-free path; the branch is workgroup-uniform
-    const bool full = cur.ty0 + TS <= p.H && cur.tx0 + TS <= p.W;
+    const bool full = cur.ty0 + TH <= p.H && cur.tx0 + TW <= p.W;
     int xlim[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) xlim[g] = p.W - cur.tx0 - (rowbase[g] & 15);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
+      const int ybase = cur.ty0 + wm * MT * 2 + mt * 2;
       if (full) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const bool yok = cur.ty0 + wm * 4 + mt * 2 + (rowbase[g] >> 4) < p.H;
+          const bool yok = ybase + (rowbase[g] >> 4) < p.H;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const bool ok = yok && k < xlim[g];
@@ -318,8 +319,7 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
           const int prow = pass * 8 + (lane >> 3);
-          const int pw = mt * 32 + prow;
-          const int gy = cur.ty0 + wm * 4 + (pw >> 4), gx = cur.tx0 + (pw & 15);
+          const int gy = ybase + (prow >> 4), gx = cur.tx0 + (prow & 15);
           if (full || (gy < p.H && gx < p.W)) {
             const uint4 v = *reinterpret_cast<const uint4*>(stg + prow * 64 + (lane & 7) * 8);
             *reinterpret_cast<uint4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv) = v;
@@ -340,8 +340,9 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
       __syncthreads();                                 // (may also drain the next item's first DMA: harmless)
       if (tid < 2 * BN) {
         const int which = tid / BN, c = tid % BN;
-        const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c] + red[(2 * 2 + which) * BN + c] +
-                        red[(3 * 2 + which) * BN + c];
+        float v = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) v += red[(m * 2 + which) * BN + c];
         p.slab[((size_t)cur.pixTile * 2 + which) * p.CoutPad + cur.co0 + c] = v;
       }
     }
@@ -351,18 +352,16 @@ __global__ __launch_bounds__(BN * 4, 2) void conv3x3_bf16_kernel(ConvP p, int nP
   }
 }
 
-template <int BN, int EPI>
+template <int BN, int MT, int NW, int EPI>
 static int launch(const ConvP& p, hipStream_t st) {
-  constexpr int W_Q = 9 * BN * 2 / 64;
-  constexpr int STAGE = HALO_BYTES + W_Q * 1024;
-  constexpr size_t lds = 2 * (size_t)STAGE + 4 * 2 * BN * sizeof(float);
-  static_assert(lds <= 160 * 1024, "LDS budget");
+  using G = Geo<BN, MT, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, MT, NW, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     attr_set = true;
   }
-  const int tilesX = ceil_div(p.W, TS), tilesY = ceil_div(p.H, TS);
+  const int tilesX = ceil_div(p.W, TW), tilesY = ceil_div(p.H, G::TH);
   ConvP q = p;
   q.tilesX = tilesX;
   q.tilesY = tilesY;
@@ -370,22 +369,34 @@ static int launch(const ConvP& p, hipStream_t st) {
   const int nPixTiles = p.N * tilesX * tilesY;
   const int nCt = p.CoutPad / BN;
   const int nItems = round_up(nPixTiles, 8) * nCt;
-  // persistent: as many workgroups as fit the chip at once (BN = 64: two per CU, BN = 128: one per CU)
-  static const int per_cu = getenv("MAU_CONV_WG_PER_CU") ? atoi(getenv("MAU_CONV_WG_PER_CU")) : (BN == 64 ? 2 : 1);
+  // persistent: as many workgroups as fit the chip at once
+  const int per_cu = (int)((160 * 1024) / G::LDS) >= 2 && NW == 4 ? 2 : 1;
   int grid = 256 * per_cu;
   if (grid > nItems) grid = nItems;                    // nItems is a multiple of 8, and so is 256*per_cu
-  MAU_LAUNCH((conv3x3_bf16_kernel<BN, EPI>), dim3(grid), dim3(BN * 4), lds, st, q, nPixTiles, nCt, nItems);
+  MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
   return check_launch("conv3x3_bf16_kernel");
+}
+
+// variant choice: the tallest tile the image height fills reasonably (tiles are TH x 16 pixels)
+static inline int tile_height(int CoutPad, int H) {
+  // Measured: the 32- and 64-row tiles move fewer LDS-DMA bytes per MFMA but their 128 accumulator
+  // registers spill and halve the resident workgroups; only the K = 13,824 decoder conv gains (+6 %), level 0
+  // loses 25 %.  Default: 16-row tiles everywhere; MAU_CONV_TH_MAX=32|64 enables the taller variants.
+  static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 16;
+  int th = CoutPad % 128 == 0 ? (H >= 32 ? 32 : 16) : (H >= 64 ? 64 : H >= 32 ? 32 : 16);
+  return th > th_max ? th_max : th;
 }
 }  // namespace v2
 
-int conv_bf16_v2_num_pixel_tiles(int N, int H, int W) { return N * ceil_div(H, v2::TS) * ceil_div(W, v2::TS); }
+int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
+  return N * ceil_div(H, v2::tile_height(round_up(Cout, 64), H)) * ceil_div(W, v2::TW);
+}
 
-template <int BN>
-static int launch_bn(const ConvP& p, hipStream_t st) {
-  if (p.post_scale != nullptr) return v2::launch<BN, v2::EPI_POST>(p, st);      // (a post-affine launch carries no slab)
-  if (p.slab != nullptr) return v2::launch<BN, v2::EPI_STATS>(p, st);
-  return v2::launch<BN, v2::EPI_PLAIN>(p, st);
+template <int BN, int MT, int NW>
+static int launch_epi(const ConvP& p, hipStream_t st) {
+  if (p.post_scale != nullptr) return v2::launch<BN, MT, NW, v2::EPI_POST>(p, st);      // (a post-affine launch carries no slab)
+  if (p.slab != nullptr) return v2::launch<BN, MT, NW, v2::EPI_STATS>(p, st);
+  return v2::launch<BN, MT, NW, v2::EPI_PLAIN>(p, st);
 }
 
 int launch_conv_bf16_v2(const ConvP& p, hipStream_t st) {
@@ -393,8 +404,9 @@ int launch_conv_bf16_v2(const ConvP& p, hipStream_t st) {
     set_error("conv3x3_fwd: post_scale/post_shift and the statistics slab are mutually exclusive");
     return MAU_ERR_ARG;
   }
-  if (p.CoutPad % 128 == 0) return launch_bn<128>(p, st);
-  return launch_bn<64>(p, st);
+  const int th = v2::tile_height(p.CoutPad, p.H);
+  if (p.CoutPad % 128 == 0) return th == 32 ? launch_epi<128, 4, 8>(p, st) : launch_epi<128, 2, 8>(p, st);
+  return th == 64 ? launch_epi<64, 4, 8>(p, st) : th == 32 ? launch_epi<64, 2, 8>(p, st) : launch_epi<64, 2, 4>(p, st);
 }
 
 }  // namespace mau

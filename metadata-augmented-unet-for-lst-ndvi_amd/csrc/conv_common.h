@@ -56,7 +56,7 @@ struct PackKC {
 };
 
 int launch_conv_bf16_v2(const ConvP& p, hipStream_t st);
-int conv_bf16_v2_num_pixel_tiles(int N, int H, int W);
+int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout);
 int launch_wgrad_bf16_v2(const WgradP& p, hipStream_t st);      // writes nsplit partial slabs (plain stores)
 int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin);
 

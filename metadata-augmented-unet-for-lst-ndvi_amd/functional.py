@@ -201,7 +201,7 @@ class ConvBNReLU(torch.autograd.Function):
         npix = N * H * W
         emb_ws = torch.empty((N, E), dtype=x.dtype, device=dev) if E else None
         if st.training:
-            tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W)
+            tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W, Cout)
             cpad = (Cout + 63) // 64 * 64
             slab = torch.empty((tiles, 2 * cpad), **f32)
             call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,

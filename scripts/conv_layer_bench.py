@@ -35,7 +35,7 @@ for name, cin, cout, h in layers:
     wf, wd = F_.pack_conv_weights(w, code, forward=True, dgrad=True)
     y = torch.empty(N, H, W, F_.pad8(cout), device="cuda", dtype=dt)
     dx = torch.empty(N, H, W, F_.pad8(cin), device="cuda", dtype=dt)
-    tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W); cpad = (cout + 63) // 64 * 64
+    tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W, cout); cpad = (cout + 63) // 64 * 64
     slab = torch.empty(tiles, 2 * cpad, device="cuda")
     acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, cout, cin), device="cuda")
     ns = lib.mau_conv3x3_wgrad_splits(code, N, H, W, cout, cin)

@@ -78,7 +78,7 @@ def test_conv3x3_exact_integers(mau, dt, shape):
     wd = dev(w)
     wf = F_.pack_conv_weights(wd, code)[0]
     y = torch.empty((N, H, W, F_.pad8(Cout)), dtype=dt, device="cuda")
-    tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W)
+    tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W, Cout)
     cpad = (Cout + 63) // 64 * 64
     slab = torch.zeros((tiles, 2 * cpad), dtype=torch.float32, device="cuda")
     call("mau_conv3x3_fwd", a.t.data_ptr(), a.t.shape[-1], Cin, None, None, 0, wf.data_ptr(), dev(b).data_ptr(), None, None, y.data_ptr(),
