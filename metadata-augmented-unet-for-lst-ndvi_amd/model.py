@@ -203,6 +203,42 @@ class UrbanPredictor_unet(_NetBase):
         return self._head(x0_1)
 
 
+    @torch.no_grad()
+    def forward_metadata_sweep(self, maps, temp_series, metadata):
+        """Eval-mode sweep over B metadata vectors for ONE tile (test/metadata_sensitivity.py:294-311, :408-419 repeat
+        the tile B times and vary only the metadata).  The encoder (src/model.py:267-273) does not see the
+        embeddings, so it runs once at batch 1; only the bottleneck and decoder run at batch B.
+        maps (1,C,H,W); temp_series (1,T) or (B,T); metadata (B,F).  Returns (B,out_channels,H,W), identical to
+        ``self(maps.expand(B,...), temp_series.expand(B,...), metadata)`` in eval mode.
+        """
+        if self.training:
+            raise RuntimeError("forward_metadata_sweep is an eval-mode path (BatchNorm must use running statistics)")
+        if maps.shape[0] != 1:
+            raise ValueError("forward_metadata_sweep expects a single tile: maps.shape[0] == 1")
+        B = metadata.shape[0]
+        if temp_series.shape[0] == 1 and B > 1:
+            temp_series = temp_series.expand(B, -1)
+        temporal_emb = self.temporal_encoder(temp_series) if self.temporal_embeddings else None
+        meta_emb = self.meta_encoder(metadata) if self.metadata_embeddings else None
+        x = Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
+        x0_0 = self.conv0_0(x)
+        x1_0 = self.conv1_0(self._pool(x0_0))
+        x2_0 = self.conv2_0(self._pool(x1_0))
+        x3_0 = self.conv3_0(self._pool(x2_0))
+        x4_0 = self._pool(x3_0)
+
+        def rep(a: Act) -> Act:          # batch broadcast of an encoder activation (data movement only)
+            return Act(a.t.expand(B, -1, -1, -1).contiguous(), a.C)
+
+        x0_0, x1_0, x2_0, x3_0, x4_0 = rep(x0_0), rep(x1_0), rep(x2_0), rep(x3_0), rep(x4_0)
+        x4_0 = self._fused_block(self.conv4_0, x4_0, [e for e in (temporal_emb, meta_emb) if e is not None])
+        x3_1 = self.conv3_1(self._up_cat(x3_0, x4_0))
+        x2_1 = self.conv2_1(self._up_cat(x2_0, x3_1))
+        x1_1 = self.conv1_1(self._up_cat(x1_0, x2_1))
+        x0_1 = self.conv0_1(self._up_cat(x0_0, x1_1))
+        return self._head(x0_1)
+
+
 class UrbanPredictor_unetpp(_NetBase):
     """src/model.py:51-193 (nested U-Net; embeddings concatenated into every decoder node)."""
 
@@ -298,6 +334,12 @@ class UrbanPredictor(nn.Module):
         return self.model(maps, temp_series, metadata)
 
     # extras forwarded to the network
+    def forward_metadata_sweep(self, maps, temp_series, metadata):
+        """One tile x B metadata vectors with the encoder computed once (U-Net only; see UrbanPredictor_unet)."""
+        if not hasattr(self.model, "forward_metadata_sweep"):
+            raise NotImplementedError("encoder reuse needs a metadata-independent encoder: model_type 'unet' only")
+        return self.model.forward_metadata_sweep(maps, temp_series, metadata)
+
     def set_precision(self, precision: str):
         self.model.set_precision(precision)
         return self

@@ -239,3 +239,23 @@ def test_multi_step_training_tracks_oracle(mau, opt_kw):
         out_eval = net(x.cuda(), ts.cuda(), md.cuda()).cpu()
         ref_eval = R.forward("unet", {k: v.detach() for k, v in sd.items()}, x, ts, md, False, **flags)
     assert rel_err(out_eval, ref_eval) < 2e-2
+
+
+@pytest.mark.parametrize("flags", [dict(temporal_embeddings=False, metadata_embeddings=True), dict(temporal_embeddings=True, metadata_embeddings=True)])
+def test_metadata_sweep_reuses_encoder(mau, flags):
+    """forward_metadata_sweep (encoder once at B=1) == the reference's way (tile repeated B times), eval mode."""
+    torch.manual_seed(5)
+    net = mau.UrbanPredictor("unet", 23, 12, 16, 8, 16, 24, 2, base_filters=8, **flags).cuda().eval()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 23, 62, 62, generator=g).cuda()
+    ts = torch.randn(1, 12, generator=g).cuda()
+    md = torch.randn(7, 8, generator=g).cuda()
+    with torch.no_grad():
+        ref = net(x.expand(7, -1, -1, -1).contiguous(), ts.expand(7, -1).contiguous(), md)
+    got = net.forward_metadata_sweep(x, ts, md)
+    assert torch.equal(got, ref)
+    net.train()
+    with pytest.raises(RuntimeError):
+        net.forward_metadata_sweep(x, ts, md)
+    with pytest.raises(NotImplementedError):
+        mau.UrbanPredictor("unet++", 23, 12, 16, 8, 16, 24, 2, base_filters=8).cuda().eval().forward_metadata_sweep(x, ts, md)
