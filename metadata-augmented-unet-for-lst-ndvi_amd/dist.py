@@ -95,7 +95,7 @@ class GradSync:
 
     def _launch(self, b: _Bucket):
         b.launched = True
-        if self.world > 1:
+        if self.group is not None:
             b.handle = all_reduce_sum(self.flat[b.lo:b.hi], self.group, async_op=True)
 
     def _on_grad(self, p: torch.nn.Parameter):

@@ -157,7 +157,7 @@ class BNState:
 
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
-    if st.group is not None and st.world > 1:
+    if st.group is not None:               # an explicitly given group is used even when it has one rank
         from .dist import all_reduce_sum
         all_reduce_sum(t, st.group)
 
@@ -209,7 +209,7 @@ class ConvBNReLU(torch.autograd.Function):
                  bias.data_ptr(), None, None, y.data_ptr(), ldy, Cout, slab.data_ptr(), code, N, H, W, stream)
             count = float(npix * st.world)
             nbt_ptr = nbt.data_ptr() if nbt is not None else None
-            if st.group is None or st.world == 1:
+            if st.group is None:
                 # single GPU: slab -> fp64 partials -> (second level + finalize) in two launches
                 ws = torch.empty(lib.mau_bn_stats_ws_elems(tiles, Cout), dtype=torch.float64, device=dev)
                 call("mau_bn_stats_finalize_train", slab.data_ptr(), tiles, count, gamma.data_ptr(), beta.data_ptr(),

@@ -65,3 +65,64 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     for key in ("rm", "rv"):
         assert float((r0[key] - one[key]).abs().max() / one[key].abs().max()) < 1e-4
         assert torch.equal(r0[key], r1[key])
+
+
+RCCL_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["MAU_ROOT"])
+import torch.distributed as dist
+import mau_amd
+from mau_amd.dist import GradSync, all_reduce_sum
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29519", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+# the collectives the data-parallel path issues, on device memory, through RCCL itself
+t64 = torch.arange(128, dtype=torch.float64, device="cuda"); all_reduce_sum(t64, dist.group.WORLD)
+t32 = torch.ones(1 << 20, device="cuda"); h = all_reduce_sum(t32[17:], dist.group.WORLD, async_op=True); h.wait()
+torch.cuda.synchronize()
+assert torch.equal(t64.cpu(), torch.arange(128, dtype=torch.float64)) and float(t32.sum()) == float(1 << 20)
+kw = dict(model_type="unet", spatial_channels=6, seq_len=10, temporal_dim=8, meta_features=4, meta_dim=8, lstm_dim=12,
+          out_channels=2, base_filters=8, temporal_embeddings=False, metadata_embeddings=True)
+g = torch.Generator().manual_seed(3)
+x = torch.randn(4, 6, 32, 32, generator=g).cuda(); ts = torch.randn(4, 10, generator=g).cuda()
+md = torch.randn(4, 4, generator=g).cuda(); tgt = torch.randn(4, 2, 32, 32, generator=g).cuda()
+res = {}
+for prec in ("fp32", "bf16"):
+    for synced in (False, True):
+        torch.manual_seed(0)
+        net = mau_amd.UrbanPredictor(**kw).cuda().set_precision(prec).train()
+        sync = None
+        if synced:
+            net.set_sync_bn(dist.group.WORLD)
+            sync = GradSync(net, dist.group.WORLD, bucket_bytes=64 << 10)
+            assert len(sync.buckets) > 1
+        for step in range(2):                       # gradients accumulate over the two passes (no optimizer: Adam
+            loss = mau_amd.compute_loss_mse(net(x, ts, md), tgt)["total"]     # would amplify rounding noise of ~0 grads)
+            if sync: sync.begin()
+            loss.backward()
+            if sync: sync.finish()
+        torch.cuda.synchronize()
+        res[(prec, synced)] = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if "running" in k}
+        res[(prec, synced)].update({"grad." + k: p.grad.float().cpu() for k, p in net.named_parameters() if p.grad is not None})
+torch.save(res, os.path.join(os.environ["MAU_OUT"], "rccl1.pt"))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_rccl_collectives_one_rank_group(tmp_path):
+    """The RCCL ("nccl") code path itself -- device-memory all-reduce of the fp64 BatchNorm sums, async bucketed
+    gradient all-reduce with handles -- on a ONE-rank group (RCCL refuses two ranks on one GPU): two forward/backward
+    passes with SyncBN + GradSync over the group must equal the same passes without a group."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, MAU_ROOT=ROOT, MAU_OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=300)
+    res = torch.load(tmp_path / "rccl1.pt")
+    # fp32: the two statistics paths (fused finalize vs reduce + all-reduce + finalize) agree to rounding;
+    # bf16: a last-bit difference in a BN scale can flip bf16 roundings downstream
+    for prec, tol in (("fp32", 1e-4), ("bf16", 3e-2)):
+        a, b = res[(prec, False)], res[(prec, True)]
+        assert a.keys() == b.keys() and len(a) > 40
+        for k in a:
+            err = float((a[k] - b[k]).abs().max())
+            assert err < tol * float(a[k].abs().max()) or err < 1e-6, (prec, k, err)
