@@ -365,23 +365,35 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 // sum of the split-K partial slabs [nsplit][9][CoutPad][CinPad] (fixed order) -> OIHW (Cout,Cin,3,3).
 // One thread per (co, ci): the nsplit x 9 reads are coalesced over ci, the 9 results are one
 // contiguous 36-byte run of the output (consecutive threads -> consecutive runs).
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ acc, int nsplit, float* __restrict__ dw,
-                                                           int Cout, int Cin, int CoutPad, int CinPad) {
-  const size_t total = (size_t)Cout * Cin;
+// acc [nsplit][9][CoutPad][CinPad] -> dw (Cout, Cin, 3, 3) = sum over the splits, in a fixed order.
+// One block = one output channel x 64 input channels: G wave-sized groups each add every G-th split slab
+// (coalesced 256-byte reads), the partial sums meet in LDS, and the 64 x 9 results leave as ONE contiguous
+// 2304-byte run of dw (the (ci, tap) order of the reference's weight tensor).
+template <int G>
+__global__ __launch_bounds__(64 * G) void unpack_wgrad_kernel(const float* __restrict__ acc, int nsplit, float* __restrict__ dw,
+                                                              int Cout, int Cin, int CoutPad, int CinPad) {
+  __shared__ float red[G][9][64];
+  const int cib = blockIdx.x % (CinPad / 64), co = blockIdx.x / (CinPad / 64);
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const size_t plane = (size_t)CoutPad * CinPad, slab = 9 * plane;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int ci = idx % Cin;
-    const int co = (int)(idx / Cin);
-    const float* src = acc + (size_t)co * CinPad + ci;
-    float v[9];
+  const float* src = acc + (size_t)co * CinPad + cib * 64 + lane;
+  float v[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) {
+  for (int t = 0; t < 9; ++t) v[t] = 0.f;
+  for (int sp = grp; sp < nsplit; sp += G) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) v[t] += src[(size_t)sp * slab + (size_t)t * plane];
-    }
+    for (int t = 0; t < 9; ++t) v[t] += src[(size_t)sp * slab + (size_t)t * plane];
+  }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) dw[idx * 9 + t] = v[t];
+  for (int t = 0; t < 9; ++t) red[grp][t][lane] = v[t];
+  __syncthreads();
+  const int nci = min(64, Cin - cib * 64);
+  for (int j = threadIdx.x; j < nci * 9; j += 64 * G) {
+    const int cl = j / 9, t = j - cl * 9;
+    float o = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) o += red[g][t][cl];
+    dw[((size_t)co * Cin + cib * 64) * 9 + j] = o;
   }
 }
 
@@ -524,9 +536,15 @@ int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* em
 
 int mau_conv3x3_unpack_wgrad(const float* acc, int nsplit, float* dw, int Cout, int Cin, mau_stream_t stream) {
   MAU_REQUIRE(acc && dw && Cout > 0 && Cin > 0 && nsplit >= 1, "unpack_wgrad: bad arguments");
-  const int grid = stream_grid((int64_t)Cout * Cin, 256);
-  MAU_LAUNCH(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, nsplit, dw, Cout, Cin,
-                     round_up(Cout, 64), round_up(Cin, 64));
+  const int CoutPad = round_up(Cout, 64), CinPad = round_up(Cin, 64);
+  const int grid = Cout * (CinPad / 64);
+  if (nsplit >= 16) {
+    MAU_LAUNCH(unpack_wgrad_kernel<16>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, acc, nsplit, dw, Cout, Cin, CoutPad, CinPad);
+  } else if (nsplit >= 4) {
+    MAU_LAUNCH(unpack_wgrad_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, nsplit, dw, Cout, Cin, CoutPad, CinPad);
+  } else {
+    MAU_LAUNCH(unpack_wgrad_kernel<1>, dim3(grid), dim3(64), 0, (hipStream_t)stream, acc, nsplit, dw, Cout, Cin, CoutPad, CinPad);
+  }
   return check_launch("unpack_wgrad_kernel");
 }
 
