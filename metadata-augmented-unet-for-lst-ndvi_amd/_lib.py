@@ -15,7 +15,7 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmau_hip.so")
+LIB_PATH = os.environ.get("MAU_LIB") or os.path.join(_HERE, "libmau_hip.so")     # MAU_LIB: A/B builds of the same ABI
 
 MAU_F32 = 0
 MAU_BF16 = 1

@@ -55,6 +55,40 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Operand-fragment reads are issued from inline asm and retired with hand-counted lgkmcnt waits.  Reason: the
+// compiler models global_load_lds as a FLAT operation touching both VMEM and LDS, and while one is pending (always,
+// in this loop) its waitcnt pass turns every LDS dependency into s_waitcnt lgkmcnt(0) -- each MFMA group then eats a
+// full LDS round trip.  Reads issued here are invisible to that pass; land<N>() is the wait, and it re-defines the
+// fragments so that their consumers cannot be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int TAP, int BN, int MT>
+__device__ __forceinline__ void fetch_tap(bf16x8 (&fb)[2], bf16x8 (&fa)[MT], unsigned b0a, unsigned b1a, const unsigned (&aa)[3]) {
+  constexpr int dy = TAP / 3, dx = TAP % 3;
+  fb[0] = lds_read128<TAP * BN * ROWB>(b0a);
+  fb[1] = lds_read128<TAP * BN * ROWB>(b1a);
+  fa[0] = lds_read128<(0 * 2 + dy) * HS * ROWB>(aa[dx]);
+  fa[1] = lds_read128<(1 * 2 + dy) * HS * ROWB>(aa[dx]);
+  if constexpr (MT == 4) {
+    fa[2] = lds_read128<(2 * 2 + dy) * HS * ROWB>(aa[dx]);
+    fa[3] = lds_read128<(3 * 2 + dy) * HS * ROWB>(aa[dx]);
+  }
+}
+// wait until at most N of this wave's LDS operations are outstanding; the fragments of the tap about to be multiplied
+template <int N, int MT>
+__device__ __forceinline__ void land(bf16x8 (&fb)[2], bf16x8 (&fa)[MT]) {
+  static_assert(MT == 2 || MT == 4, "fragment count");
+  if constexpr (MT == 2)
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fa[0]), "+v"(fa[1]) : "n"(N));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]) : "n"(N));
+}
+
 // One (pixel tile, cout tile) work item.
 struct Item {
   int pixTile, n, ty0, tx0, co0;
@@ -68,7 +102,7 @@ constexpr int EPI_POST = 2;    // y = relu(scale*(conv+bias) + shift)   : infere
 // Geometry of a variant: NW waves = WM (pixel direction) x WN (= BN/64 channel direction); a wave owns
 // MT x 32 pixels (MT x 2 tile rows of 16) x 64 channels = MT x 2 accumulator tiles of 32x32.
 //   <128, 2, 8>: 16x16 px tile     <128, 4, 8>: 32x16 px tile (128 accumulator registers per lane)
-//   < 64, 2, 4>: 16x16             < 64, 2, 8>: 32x16            < 64, 4, 8>: 64x16
+//   < 64, 2, 4>: 16x16             < 64, 2, 8>: 32x16
 // Larger tiles move fewer LDS-DMA bytes per MFMA (weights are shared by more pixels, the halo by more
 // channels): the ablation in DESIGN.md prices each DMA stream at ~12 % of the kernel time.
 template <int BN, int MT, int NW>
@@ -80,8 +114,9 @@ struct Geo {
   static constexpr int HALO_BYTES = HALO_Q * 1024;
   static constexpr int W_Q = 9 * BN * 2 / 64;                  // wave-DMAs for the weight slab
   static constexpr int TOT_Q = HALO_Q + W_Q;
-  static constexpr int STAGE = HALO_BYTES + W_Q * 1024;        // bytes per LDS stage
-  static constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;
+  static constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;       // every wave issues exactly PER_WAVE DMAs per stage:
+  static constexpr int STAGE = PER_WAVE * NW * 1024;           // slots >= TOT_Q are padding fed from the zero page
+  static_assert(PER_WAVE <= 9, "one DMA per tap");
   static constexpr int RED_OFF = 2 * STAGE;
   static constexpr size_t LDS = 2 * (size_t)STAGE + (size_t)WM * 2 * BN * sizeof(float);
   static_assert(NW % WN == 0 && (size_t)NW * 32 * 64 * 2 <= STAGE, "epilogue staging must fit one stage buffer");
@@ -127,29 +162,42 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     return -1;
   };
 
-  // ---- per-lane DMA slots: the tile-independent part ----
+  // ---- per-lane DMA slots: the tile-independent part.  The address of a wave-DMA is computed WITHOUT
+  // control flow (selects only), so that the tap sequence of a stage stays one basic block and the
+  // compiler's waitcnt pass can count outstanding ds_reads instead of draining them. ----
   int slot_hp[PER_WAVE];            // halo: pixel index inside the halo tile (or -1); weights: row = tap*BN + co
   int slot_c[PER_WAVE];             // 8 * logical 16-byte half
+  int s_limt[PER_WAVE];             // wave-uniform: channels [0, limt) come from the tensor source ...
+  int s_E[PER_WAVE];                // ... [C0, C0 + E) from the broadcast embedding, everything else from the zero page
+  size_t s_stride[PER_WAVE];        // elements per K chunk along the tensor source
+  const size_t w_stage_stride = (size_t)9 * p.CoutPad * KC;
 #pragma unroll
   for (int j = 0; j < PER_WAVE; ++j) {
     const int q = wave + j * NW;
     slot_hp[j] = -1;
     slot_c[j] = 0;
+    s_limt[j] = 0;
+    s_E[j] = 0;
+    s_stride[j] = 0;
     if (q < HALO_Q) {
       const int slot = q * 64 + lane;
       const int hp = slot >> 1, ph = slot & 1;
       slot_c[j] = 8 * (ph ^ halo_swz(hp % HS));
       slot_hp[j] = hp < HPIX ? hp : -1;
+      s_limt[j] = p.E == 0 ? p.ldx : p.C0;
+      s_E[j] = p.E;
+      s_stride[j] = KC;
     } else if (q < TOT_Q) {
       const int slot = (q - HALO_Q) * 64 + lane;
       const int row = slot >> 1, ph = slot & 1;
       slot_c[j] = 8 * (ph ^ ((row >> 3) & 1));
       slot_hp[j] = row;
+      s_limt[j] = 0x7fffffff;
+      s_stride[j] = w_stage_stride;
     }
   }
-  const size_t w_stage_stride = (size_t)9 * p.CoutPad * KC;
 
-  // source descriptors of the item being LOADED (constant over its stages)
+  // source descriptors of the item being LOADED (constant over its stages); nullptr = zero page
   const bf16* src_base[PER_WAVE];
   const bf16* embn = nullptr;
   auto setup = [&](const Item& it) {
@@ -162,7 +210,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
         const int hp = slot_hp[j];
         if (hp >= 0) {
           const int gy = it.ty0 + hp / HS - 1, gx = it.tx0 + hp % HS - 1;
-          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) src_base[j] = xg + ((size_t)(it.n * p.H + gy) * p.W + gx) * (size_t)p.ldx;
+          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+            src_base[j] = xg + ((size_t)(it.n * p.H + gy) * p.W + gx) * (size_t)p.ldx + slot_c[j];
         }
       } else if (q < TOT_Q) {
         const int row = slot_hp[j];
@@ -171,25 +220,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
       }
     }
   };
+  // one wave-DMA (1 KiB) of a stage; j is a compile-time constant after unrolling
+  auto issue_slot = [&](int j, int stage, int chunk) {
+    const int q = wave + j * NW;                      // wave-uniform
+    const int c = chunk * KC + slot_c[j];
+    const bool valid = src_base[j] != nullptr;
+    const bf16* pt = src_base[j] + (size_t)chunk * s_stride[j];
+    const bf16* pe = embn + (c - p.C0);
+    const bool is_t = valid & (c < s_limt[j]);
+    const bool is_e = valid & ((unsigned)(c - p.C0) < (unsigned)s_E[j]);
+    const bf16* src = is_t ? pt : (is_e ? pe : zero);
+    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + stage * STAGE + q * 1024), 16, 0, 0);
+  };
   auto issue = [&](int stage, int chunk) {
-    const int c0 = chunk * KC;
 #pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
-      const int q = wave + j * NW;                    // wave-uniform
-      if (q < TOT_Q) {
-        const bf16* src = zero;
-        if (q < HALO_Q) {
-          const int c = c0 + slot_c[j];
-          if (src_base[j] != nullptr) {
-            if (c < p.C0 || (p.E == 0 && c < p.ldx)) src = src_base[j] + c;
-            else if (c < p.C0 + p.E) src = embn + (c - p.C0);
-          }
-        } else {
-          src = src_base[j] + (size_t)chunk * w_stage_stride;
-        }
-        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + stage * STAGE + q * 1024), 16, 0, 0);
-      }
-    }
+    for (int j = 0; j < PER_WAVE; ++j) issue_slot(j, stage, chunk);
   };
 
   // ---- per-lane LDS read addresses: three bases (one per dx) + immediates for (mt, dy); two for the weights ----
@@ -208,6 +253,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
 #pragma unroll
   for (int g = 0; g < 4; ++g) rowbase[g] = perm32(8 * g + 4 * h);
 
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);   // LDS byte address of smem
   Item cur, nxt;
   int I = next_valid(blockIdx.x, cur);
   if (I < 0) return;                                  // whole workgroup leaves before any barrier
@@ -233,25 +279,39 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     for (int chunk = 0; chunk < p.nChunks; ++chunk) {
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      if (chunk + 1 < p.nChunks) {
-        issue(stage ^ 1, chunk + 1);
-      } else if (In >= 0) {
-        setup(nxt);
-        issue(stage ^ 1, 0);
-      }
-      const unsigned char* sb = smem + stage * STAGE;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap % 3;
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + boff0 + tap * BN * ROWB);
-        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + boff1 + tap * BN * ROWB);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(sb + abase[dx] + (mt * 2 + dy) * HS * ROWB);
-          acc[mt][0] = mfma32(a, b0, acc[mt][0]);
-          acc[mt][1] = mfma32(a, b1, acc[mt][1]);
-        }
-      }
+      // next stage: the following chunk of this item, or chunk 0 of the next item (cross-tile pipelining);
+      // after the very last stage chunk 0 of the current item is re-fetched into the idle buffer (nobody reads it)
+      const bool more = chunk + 1 < p.nChunks;
+      const int fchunk = more ? chunk + 1 : 0;
+      if (!more && In >= 0) setup(nxt);
+      // Operand fragments are double-buffered in registers: the ds_reads of tap t+1 are issued BEFORE the
+      // MFMAs of tap t, so the only LDS round trip a wave waits out is the first one of a stage (timing
+      // ablation, DESIGN.md: with the reads removed the same loop runs 1.36x faster).
+      // The following stage's DMAs are issued ONE PER TAP, after the MFMA group: a wave-DMA costs its issuing
+      // wave 60-185 cycles (MI355X_MICROARCH.md); in a burst at the head of the stage all eight waves would
+      // pay that with the MFMA pipes idle, spread out the SIMD's other wave multiplies meanwhile.
+      const unsigned sbase = lds0 + stage * STAGE;
+      const unsigned b0a = sbase + boff0, b1a = sbase + boff1;
+      const unsigned aa[3] = {sbase + abase[0], sbase + abase[1], sbase + abase[2]};
+      bf16x8 fb[2][2], fa[2][MT];
+      fetch_tap<0, BN, MT>(fb[0], fa[0], b0a, b1a, aa);
+#define MAU_TAP(T)                                                                    \
+  {                                                                                   \
+    constexpr int cs = (T)&1;                                                         \
+    if constexpr ((T) < 8) fetch_tap<((T) < 8 ? (T) + 1 : 0), BN, MT>(fb[cs ^ 1], fa[cs ^ 1], b0a, b1a, aa); \
+    land<((T) < 8 ? 2 + MT : 0), MT>(fb[cs], fa[cs]);                                 \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                               \
+      acc[mt][0] = mfma32(fa[cs][mt], fb[cs][0], acc[mt][0]);                         \
+      acc[mt][1] = mfma32(fa[cs][mt], fb[cs][1], acc[mt][1]);                         \
+    }                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                \
+    if constexpr ((T) < PER_WAVE) {                                                   \
+      issue_slot((T), stage ^ 1, fchunk);                                             \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+    }                                                                                 \
+  }
+      MAU_TAP(0) MAU_TAP(1) MAU_TAP(2) MAU_TAP(3) MAU_TAP(4) MAU_TAP(5) MAU_TAP(6) MAU_TAP(7) MAU_TAP(8)
+#undef MAU_TAP
       stage ^= 1;
     }
 
@@ -350,6 +410,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     cur = nxt;
     I = In;
   }
+  wait_vmcnt<0>();                                     // the idle re-fetch of the last stage must land before the LDS is released
 }
 
 template <int BN, int MT, int NW, int EPI>
@@ -377,19 +438,33 @@ static int launch(const ConvP& p, hipStream_t st) {
   return check_launch("conv3x3_bf16_kernel");
 }
 
-// variant choice: the tallest tile the image height fills reasonably (tiles are TH x 16 pixels)
-static inline int tile_height(int CoutPad, int H) {
-  // Measured: the 32- and 64-row tiles move fewer LDS-DMA bytes per MFMA but their 128 accumulator
-  // registers spill and halve the resident workgroups; only the K = 13,824 decoder conv gains (+6 %), level 0
-  // loses 25 %.  Default: 16-row tiles everywhere; MAU_CONV_TH_MAX=32|64 enables the taller variants.
-  static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 16;
-  int th = CoutPad % 128 == 0 ? (H >= 32 ? 32 : 16) : (H >= 64 ? 64 : H >= 32 ? 32 : 16);
-  return th > th_max ? th_max : th;
+// Variant choice.  Taller workgroup tiles move fewer LDS-DMA bytes and issue fewer ds_reads per MFMA (measured
+// +5..9 % on full grids), but quarter the number of work items: a layer whose items do not fill the 256 CUs (or that
+// wastes tile rows on a small image) is better off with 16-row tiles.  Score = grid-fill x tile-fill x variant bonus.
+static inline int tile_height(int CoutPad, int N, int H, int W) {
+  static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 32;
+  const bool wide = CoutPad % 128 == 0;
+  const int nCt = CoutPad / (wide ? 128 : 64);
+  int best = 16;
+  double best_score = -1.0;
+  for (int th = 16; th <= 32 && th <= th_max; th *= 2) {
+    const int slots = 256 * ((!wide && th == 16) ? 2 : 1);         // <64,2,4> runs two workgroups per CU
+    const long tilesY = ceil_div(H, th), tilesX = ceil_div(W, TW);
+    const long items = (long)N * tilesY * tilesX * nCt;
+    const double grid_fill = (double)items / (double)(((items + slots - 1) / slots) * slots);
+    const double tile_fill = (double)H * W / (double)(tilesY * th * tilesX * TW);
+    const double score = grid_fill * tile_fill * (th == 32 ? 1.06 : 1.0);
+    if (score > best_score) {
+      best_score = score;
+      best = th;
+    }
+  }
+  return best;
 }
 }  // namespace v2
 
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
-  return N * ceil_div(H, v2::tile_height(round_up(Cout, 64), H)) * ceil_div(W, v2::TW);
+  return N * ceil_div(H, v2::tile_height(round_up(Cout, 64), N, H, W)) * ceil_div(W, v2::TW);
 }
 
 template <int BN, int MT, int NW>
@@ -404,9 +479,9 @@ int launch_conv_bf16_v2(const ConvP& p, hipStream_t st) {
     set_error("conv3x3_fwd: post_scale/post_shift and the statistics slab are mutually exclusive");
     return MAU_ERR_ARG;
   }
-  const int th = v2::tile_height(p.CoutPad, p.H);
+  const int th = v2::tile_height(p.CoutPad, p.N, p.H, p.W);
   if (p.CoutPad % 128 == 0) return th == 32 ? launch_epi<128, 4, 8>(p, st) : launch_epi<128, 2, 8>(p, st);
-  return th == 64 ? launch_epi<64, 4, 8>(p, st) : th == 32 ? launch_epi<64, 2, 8>(p, st) : launch_epi<64, 2, 4>(p, st);
+  return th == 32 ? launch_epi<64, 2, 8>(p, st) : launch_epi<64, 2, 4>(p, st);
 }
 
 }  // namespace mau
