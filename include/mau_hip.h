@@ -56,6 +56,18 @@ int mau_nchw_to_nhwc(const float* src, void* dst, int dtype, int N, int C, int H
 int mau_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H, int W, int ld,
                      mau_stream_t stream);
 
+/* Input pipeline (reference src/dataset.py:53-72 hands over 23 fp32 planes per tile, 18 of them the one-hot
+ * expansion of two class maps, src/data/processing_10m/process.py:176-181 + normalization.py:96-100): the class maps
+ * travel as uint8 (N,H,W) and the one-hot channels are generated on the device.
+ * out (N,H,W,ldo) = [onehot(cls_a) num_classes | cont (N,ncont,H,W) fp32 | onehot(cls_b) num_classes | zero pad];
+ * flip (N) uint8 or NULL: nonzero mirrors that tile along W (RandomFlip, src/dataset.py:134-141). ncont <= 8. */
+int mau_pack_tile_onehot(const unsigned char* cls_a, const unsigned char* cls_b, const float* cont,
+                         const unsigned char* flip, void* out, int ldo, int dtype, int N, int H, int W,
+                         int num_classes, int ncont, mau_stream_t stream);
+/* dst[n,c,y,x] = src[n,c,y, flip[n] ? W-1-x : x]: the target half of RandomFlip (src/dataset.py:139). */
+int mau_flip_rows(const float* src, float* dst, const unsigned char* flip, int N, int C, int H, int W,
+                  mau_stream_t stream);
+
 /* ---- 3x3 convolution, stride 1, pad 1 (nn.Conv2d(.,.,3,padding=1), src/model.py:12,14) ---- */
 /* Channel-chunk size of the packed weights for `dtype` (K-chunk of the implicit GEMM). */
 int mau_conv3x3_kc(int dtype);

@@ -28,6 +28,8 @@ PROTOTYPES = {
     "mau_last_error": (C.c_char_p, []),
     "mau_device_check": (_i, []),
     "mau_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_pack_tile_onehot": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_flip_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "mau_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_conv3x3_kc": (_i, [_i]),
     "mau_conv3x3_packed_elems": (_sz, [_i, _i, _i]),

@@ -44,6 +44,52 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
     if (c0 + j < C) dst[((size_t)n * C + c0 + j) * HW + p] = v.v[j];
 }
 
+// ---- compact tile -> network input (input pipeline, reference src/dataset.py:53-72 + processing_10m/process.py:176-181) ----
+// The reference stores and ships 23 fp32 planes per tile of which 18 are the one-hot expansion of two 9-class maps.
+// Here the two class maps travel as uint8 and the one-hot channels are generated while the NHWC-ld tensor is written:
+// out[n, y, x, :] = [onehot(cls_a) | cont[0..ncont) | onehot(cls_b) | 0 pad], x mirrored when flip[n] != 0 (RandomFlip).
+// grid = (x chunks, rows, images); one thread per pixel, 16-byte channel-group stores.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_tile_onehot_kernel(const uint8_t* __restrict__ cls_a, const uint8_t* __restrict__ cls_b,
+                                                               const float* __restrict__ cont, const uint8_t* __restrict__ flip,
+                                                               T* __restrict__ out, int ld, int H, int W, int nc, int ncont) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const int y = blockIdx.y, n = blockIdx.z;
+  const int xs = (flip != nullptr && flip[n]) ? W - 1 - x : x;
+  const size_t hw = (size_t)H * W, ps = (size_t)y * W + xs;
+  const int a = cls_a[n * hw + ps], b = cls_b[n * hw + ps];
+  float cv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cv[j] = j < ncont ? cont[((size_t)n * ncont + j) * hw + ps] : 0.f;
+  T* o = out + ((size_t)n * hw + (size_t)y * W + x) * ld;
+  for (int g = 0; g < ld; g += 8) {
+    F8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = g + j;
+      float f = 0.f;
+      if (c < nc) f = (a == c) ? 1.f : 0.f;
+      else if (c < nc + ncont) {
+        const int k = c - nc;
+        f = k == 0 ? cv[0] : k == 1 ? cv[1] : k == 2 ? cv[2] : k == 3 ? cv[3] : k == 4 ? cv[4] : k == 5 ? cv[5] : k == 6 ? cv[6] : cv[7];
+      } else if (c < 2 * nc + ncont) f = (b == c - nc - ncont) ? 1.f : 0.f;
+      v.v[j] = f;
+    }
+    store8<T>(o + g, v);
+  }
+}
+
+// dst[n,c,y,x] = src[n,c,y, flip[n] ? W-1-x : x]   (the target half of RandomFlip, src/dataset.py:139)
+__global__ __launch_bounds__(256) void flip_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, const uint8_t* __restrict__ flip,
+                                                        int rows_per_image, int W) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const int n = blockIdx.z;
+  const size_t row = ((size_t)n * rows_per_image + blockIdx.y) * W;
+  dst[row + x] = src[row + (flip[n] ? W - 1 - x : x)];
+}
+
 // ---- MaxPool2d(2,2), floor mode -------------------------------------------------------------
 // grid = (x-chunks of the output row, output rows, images): no 64-bit div/mod per element
 template <typename T>
@@ -317,6 +363,26 @@ int mau_nhwc_to_nchw(const void* src, float* dst, int dtype, int N, int C, int H
   dim3 grid(ceil_div(HW, 256), ceil_div(C, 8), N);
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, dst, C, HW, ld));
   return check_launch("nhwc_to_nchw_kernel");
+}
+
+int mau_pack_tile_onehot(const unsigned char* cls_a, const unsigned char* cls_b, const float* cont, const unsigned char* flip,
+                         void* out, int ldo, int dtype, int N, int H, int W, int num_classes, int ncont, mau_stream_t stream) {
+  MAU_REQUIRE(cls_a && cls_b && out && N > 0 && H > 0 && W > 0, "pack_tile_onehot: bad arguments");
+  MAU_REQUIRE(num_classes >= 1 && num_classes <= 255 && ncont >= 0 && ncont <= 8 && (ncont == 0 || cont), "pack_tile_onehot: bad channel counts");
+  MAU_REQUIRE(ldo % 8 == 0 && ldo >= 2 * num_classes + ncont, "pack_tile_onehot: bad ld");
+  MAU_REQUIRE(H <= 65535 && N <= 65535, "pack_tile_onehot: H and N must fit a grid dimension");
+  dim3 grid(ceil_div(W, 256), H, N);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(pack_tile_onehot_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, cls_a, cls_b, cont, flip,
+                                       (T*)out, ldo, H, W, num_classes, ncont));
+  return check_launch("pack_tile_onehot_kernel");
+}
+
+int mau_flip_rows(const float* src, float* dst, const unsigned char* flip, int N, int C, int H, int W, mau_stream_t stream) {
+  MAU_REQUIRE(src && dst && flip && src != dst && N > 0 && C > 0 && H > 0 && W > 0, "flip_rows: bad arguments");
+  MAU_REQUIRE((int64_t)C * H <= 65535 && N <= 65535, "flip_rows: C*H and N must fit a grid dimension");
+  dim3 grid(ceil_div(W, 256), C * H, N);
+  MAU_LAUNCH(flip_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, flip, C * H, W);
+  return check_launch("flip_rows_kernel");
 }
 
 int mau_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int N, int H, int W, int C, mau_stream_t stream) {

@@ -131,6 +131,15 @@ class _NetBase(nn.Module):
         self._rt.world = world_size if world_size is not None else dist.get_world_size(g)
         return self
 
+    def _entry(self, maps) -> Act:
+        """maps: (B,C,H,W) fp32 as the reference's collate_fn delivers it, or an ``Act`` already in the network's
+        layout and dtype (``mau_amd.data``: one-hot channels generated on the device)."""
+        if isinstance(maps, Act):
+            if maps.t.dtype != self._rt.dtype:
+                raise RuntimeError(f"packed input is {maps.t.dtype}, the network computes in {self._rt.dtype}")
+            return maps
+        return Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
+
     def _pool(self, a: Act) -> Act:
         return Act(F_.MaxPool2x2.apply(a.t, a.C), a.C)
 
@@ -189,7 +198,7 @@ class UrbanPredictor_unet(_NetBase):
     def forward(self, maps, temp_series, metadata):
         temporal_emb = self.temporal_encoder(temp_series) if self.temporal_embeddings else None
         meta_emb = self.meta_encoder(metadata) if self.metadata_embeddings else None
-        x = Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
+        x = self._entry(maps)
         x0_0 = self.conv0_0(x)
         x1_0 = self.conv1_0(self._pool(x0_0))
         x2_0 = self.conv2_0(self._pool(x1_0))
@@ -220,7 +229,7 @@ class UrbanPredictor_unet(_NetBase):
             temp_series = temp_series.expand(B, -1)
         temporal_emb = self.temporal_encoder(temp_series) if self.temporal_embeddings else None
         meta_emb = self.meta_encoder(metadata) if self.metadata_embeddings else None
-        x = Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
+        x = self._entry(maps)
         x0_0 = self.conv0_0(x)
         x1_0 = self.conv1_0(self._pool(x0_0))
         x2_0 = self.conv2_0(self._pool(x1_0))
@@ -288,7 +297,7 @@ class UrbanPredictor_unetpp(_NetBase):
         temporal_emb = self.temporal_encoder(temp_series)
         meta_emb = self.meta_encoder(metadata)
         emb = torch.cat([temporal_emb, meta_emb], dim=1).float()           # src/model.py:103
-        x = Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
+        x = self._entry(maps)
         x0_0 = self.conv0_0(x)
         x1_0 = self.conv1_0(self._pool(x0_0))
         x0_1 = self._node(self.conv0_1, [x0_0], x1_0, emb)

@@ -4,6 +4,8 @@ keeps the reference's constructor / state_dict / error contract."""
 import os
 import re
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -33,7 +35,10 @@ def test_library_exports_every_header_symbol():
     # pure host-side helpers of the ABI are callable without a GPU
     assert _lib.lib.mau_conv3x3_kc(_lib.MAU_BF16) == 16 and _lib.lib.mau_conv3x3_kc(_lib.MAU_F32) == 16
     assert _lib.lib.mau_conv3x3_packed_elems(_lib.MAU_BF16, 64, 6) == 1 * 9 * 64 * 16
-    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 256, 256, 64) == 32 * 16 * 16
+    # bf16 tile height is chosen per layer (grid fill): 32-row tiles on a full grid, 16-row tiles when the layer is small
+    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 256, 256, 64) == 32 * 8 * 16
+    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 32, 32, 256) == 32 * 2 * 2
+    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 2, 16, 16, 1024) == 2
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 16, 16, 1024) == 32
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_F32, 2, 250, 250, 64) == 2 * 32 * 16
     s = _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 32, 32, 512, 1536)
@@ -160,3 +165,73 @@ def test_checkpoint_reader_rules_and_roundtrip(tmp_path):
     # bare state_dict and 'state_dict' variants (app/model_utils.py:91-96)
     torch.save({"state_dict": net.state_dict(), "hyperparameters": hyper, "metadata_input_length": 8}, path)
     C.load_model(path, device="cpu")
+
+
+# --------------------------------------------------------------------------- #
+# input pipeline (host logic; the device kernel is covered in tests/test_gpu_ops.py)
+# --------------------------------------------------------------------------- #
+def _fake_tile(rng, H=20, W=18, nc=9):
+    a = rng.integers(0, nc, (H, W)); b = rng.integers(0, nc, (H, W))
+    cont = rng.standard_normal((5, H, W)).astype(np.float32)
+    dense = np.vstack([np.eye(nc)[a].transpose(2, 0, 1), cont, np.eye(nc)[b].transpose(2, 0, 1)]).astype(np.float32)   # process.py:181
+    return a, b, cont, dense
+
+
+def test_compact_input_roundtrip_and_validation():
+    import mau_amd
+    rng = np.random.default_rng(0)
+    a, b, cont, dense = _fake_tile(rng)
+    ca, cb, cc = mau_amd.data.compact_input(dense)
+    assert ca.dtype == np.uint8 and np.array_equal(ca, a) and np.array_equal(cb, b) and np.array_equal(cc, cont)
+    assert np.array_equal(mau_amd.data.expand_input(ca, cb, cc), dense)
+    bad = dense.copy(); bad[0, 0, 0] = 0.5
+    with pytest.raises(ValueError):
+        mau_amd.data.compact_input(bad)
+    bad = dense.copy(); bad[:9, 3, 3] = 0
+    with pytest.raises(ValueError):
+        mau_amd.data.compact_input(bad)
+
+
+def test_random_flip_draws_follow_the_reference_stream():
+    """src/dataset.py:134-141: random.seed(seed) at construction, one random.random() < 0.5 per sample."""
+    import random
+    import mau_amd
+    rf = mau_amd.data.RandomFlip(seed=42)
+    got = [rf.draw() for _ in range(64)]
+    random.seed(42)
+    assert got == [random.random() < 0.5 for _ in range(64)] and 10 < sum(got) < 54
+    rf = mau_amd.data.RandomFlip(seed=7)
+    x = np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4); y = x[:1] * 2
+    random.seed(7); want = random.random() < 0.5
+    fx, fy = rf(x, y)
+    assert np.array_equal(fx, np.flip(x, 2) if want else x) and np.array_equal(fy, np.flip(y, 2) if want else y)
+
+
+def test_dataset_and_collate_mirror_the_reference_contract(tmp_path):
+    import mau_amd
+    rng = np.random.default_rng(1)
+    d = tmp_path / "train"; d.mkdir()
+    dense = {}
+    for i, n_ts in enumerate((12, 9, 12)):
+        a, b, cont, x = _fake_tile(rng)
+        name = f"Some City_{i}_48.8566_2.3522_2019_0{i + 1}_to_2021_0{i + 2}.npz"     # process.py:158
+        np.savez_compressed(d / name, input=x, target=rng.standard_normal((2, 20, 18)).astype(np.float32),
+                            metadata=rng.standard_normal(4).astype(np.float32), temperature_serie=rng.standard_normal(n_ts).astype(np.float32))
+        dense[name] = x
+    with pytest.raises(FileNotFoundError):
+        mau_amd.data.FuturePredictionDataset("val", processed_dir=str(tmp_path))
+    ref_like = mau_amd.data.FuturePredictionDataset("train", processed_dir=str(tmp_path), compact=False)
+    assert len(ref_like) == 3
+    x0, md0, ts0, t1, t2, tg0 = ref_like[0]
+    assert x0.shape == (23, 20, 18) and t1.tolist() == [2019.0, 1.0] and t2.tolist() == [2021.0, 2.0] and tg0.shape == (2, 20, 18)
+    assert ref_like.get_metadata_from_idx(0) == {"city": "Some City", "lat": 48.8566, "lon": 2.3522}
+    ds = mau_amd.data.FuturePredictionDataset("train", processed_dir=str(tmp_path), transform=mau_amd.data.RandomFlip(3))
+    batch = mau_amd.data.collate_fn([ds[i] for i in range(3)])
+    assert batch.cls_a.dtype == torch.uint8 and batch.cls_a.shape == (3, 20, 18) and batch.cont.shape == (3, 5, 20, 18)
+    assert batch.temp_series.shape == (3, 12) and batch.temp_series_lengths.tolist() == [12, 9, 12] and float(batch.temp_series[1, 9:].abs().sum()) == 0
+    assert batch.flip.dtype == torch.uint8 and batch.targets.shape == (3, 2, 20, 18)
+    for i in range(3):
+        x = mau_amd.data.expand_input(batch.cls_a[i].numpy(), batch.cls_b[i].numpy(), batch.cont[i].numpy())
+        assert np.array_equal(x, ref_like[i][0].numpy())
+    dense_bytes = 3 * (23 + 2) * 20 * 18 * 4
+    assert batch.host_bytes() < 0.4 * dense_bytes

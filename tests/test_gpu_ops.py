@@ -325,3 +325,68 @@ def test_g9_loss_suite(mau):
         assert rel_err(o2.grad.cpu(), t(d[f"{tag}/d_l1_gradient"])) < 1e-5          # SSIM carries no gradient (losses.py:96)
         assert 0.0 <= float(r2["ssim"]) <= 2.0
         assert float(mau.gradient_loss(o2.detach(), tg)["gradient"]) == pytest.approx(float(d[f"{tag}/gradient"][0]), rel=1e-5)
+
+
+# --------------------------------------------------------------------------- #
+# input pipeline kernel
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 20, 18), (2, 250, 250), (1, 7, 300)])
+def test_pack_tile_onehot_matches_dense_path(mau, dt, shape):
+    """uint8 class maps + 5 planes (+ flip flags) -> exactly what the reference's dense 23-plane input gives after
+    RandomFlip (np.flip along W, src/dataset.py:138-139) and the module's own NCHW->NHWC-ld entry conversion."""
+    from mau_amd import functional as F_
+    B, H, W = shape
+    rng = np.random.default_rng(B * 1000 + W)
+    a = rng.integers(0, 9, (B, H, W)).astype(np.uint8); b = rng.integers(0, 9, (B, H, W)).astype(np.uint8)
+    cont = rng.standard_normal((B, 5, H, W)).astype(np.float32)
+    flip = (rng.random(B) < 0.5).astype(np.uint8); flip[0] = 1
+    tgt = rng.standard_normal((B, 2, H, W)).astype(np.float32)
+    dense = np.stack([mau.data.expand_input(a[i], b[i], cont[i]) for i in range(B)])
+    dense_f = np.stack([np.flip(dense[i], 2) if flip[i] else dense[i] for i in range(B)]).copy()
+    tgt_f = np.stack([np.flip(tgt[i], 2) if flip[i] else tgt[i] for i in range(B)]).copy()
+    want = F_.ToNHWC.apply(torch.from_numpy(dense_f).cuda(), dt)
+    dev = [torch.from_numpy(v).cuda() for v in (a, b, cont, flip)]
+    got = mau.data.pack_tiles(*dev, dt)
+    assert got.C == 23 and got.t.shape == want.shape and torch.equal(got.t, want)
+    assert torch.equal(mau.data.pack_tiles(dev[0], dev[1], dev[2], None, dt).t, F_.ToNHWC.apply(torch.from_numpy(dense).cuda(), dt))
+    assert torch.equal(mau.data.flip_targets(torch.from_numpy(tgt).cuda(), dev[3]).cpu(), torch.from_numpy(tgt_f))
+
+
+def test_packed_input_feeds_the_network(mau):
+    torch.manual_seed(2)
+    net = mau.UrbanPredictor("unet", 23, 12, 16, 4, 16, 24, 2, base_filters=8, temporal_embeddings=False).cuda().eval()
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 9, (2, 36, 40)).astype(np.uint8); b = rng.integers(0, 9, (2, 36, 40)).astype(np.uint8)
+    cont = rng.standard_normal((2, 5, 36, 40)).astype(np.float32)
+    dense = torch.from_numpy(np.stack([mau.data.expand_input(a[i], b[i], cont[i]) for i in range(2)])).cuda()
+    ts, md = torch.randn(2, 12).cuda(), torch.randn(2, 4).cuda()
+    packed = mau.data.pack_tiles(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(cont).cuda(), None, torch.bfloat16)
+    with torch.no_grad():
+        assert torch.equal(net(packed, ts, md), net(dense, ts, md))
+        with pytest.raises(RuntimeError):
+            net.set_precision("fp32")(packed, ts, md)          # dtype of the packed input must match the network's
+
+
+def test_device_loader_prefetches_compact_batches(mau, tmp_path):
+    d = tmp_path / "train"; d.mkdir()
+    rng = np.random.default_rng(9)
+    for i in range(5):
+        a = rng.integers(0, 9, (24, 24)); b = rng.integers(0, 9, (24, 24))
+        x = np.vstack([np.eye(9)[a].transpose(2, 0, 1), rng.standard_normal((5, 24, 24)), np.eye(9)[b].transpose(2, 0, 1)]).astype(np.float32)
+        np.savez_compressed(d / f"City_{i}_1.0000_2.0000_2019_01_to_2021_02.npz", input=x, target=rng.standard_normal((2, 24, 24)).astype(np.float32),
+                            metadata=rng.standard_normal(4).astype(np.float32), temperature_serie=rng.standard_normal(12).astype(np.float32))
+    ref = mau.data.FuturePredictionDataset("train", processed_dir=str(tmp_path), compact=False, transform=mau.data.RandomFlip(11))
+    want = [ref[i] for i in range(5)]                                         # host transform, reference style
+    loader = mau.data.create_dataloader("train", 2, False, transform=mau.data.RandomFlip(11), processed_dir=str(tmp_path),
+                                        device="cuda", dtype=torch.float32)
+    from mau_amd import functional as F_
+    seen = 0
+    for inputs, md, ts, lens, t1, t2, tg in loader:
+        n = md.shape[0]
+        dense = torch.stack([want[seen + i][0] for i in range(n)]).cuda()
+        assert torch.equal(inputs.t, F_.ToNHWC.apply(dense, torch.float32))
+        assert torch.equal(tg.cpu(), torch.stack([want[seen + i][5] for i in range(n)]))
+        assert torch.equal(md.cpu(), torch.stack([want[seen + i][1] for i in range(n)]))
+        seen += n
+    assert seen == 5 and len(loader) == 3
