@@ -116,6 +116,10 @@ int mau_conv3x3_unpack_wgrad(const float* acc, int nsplit, float* dw_oihw, int C
 size_t mau_reduce_rows_ws_elems(int rows, int M);
 int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, double* ws,
                         mau_stream_t stream);
+/* same, and additionally the sums rounded to fp32 in `sums32` (the BatchNorm weight/bias gradients that autograd
+ * returns, next to the fp64 sums the backward formula uses). */
+int mau_reduce_rows_f64_f32(const float* slab, int rows, int M, int ldrow, double* sums, float* sums32,
+                            double* ws, mau_stream_t stream);
 /* same, result rounded to fp32. */
 int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, double* ws,
                         mau_stream_t stream);
@@ -159,6 +163,10 @@ int mau_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int 
 /* dx (N,H,W) = scatter of dy (N,H/2,W/2) to the first maximum of each window; rest zero. */
 int mau_maxpool2x2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int dtype,
                        int N, int H, int W, int C, mau_stream_t stream);
+/* dx = dskip + maxpool2x2 backward: x feeds the pool AND a skip connection (src/model.py:268-271 / :279-282); the two
+ * gradients autograd would add in a separate pass are combined while dx is written. */
+int mau_maxpool2x2_bwd_add(const void* x, int ldx, const void* dy, int lddy, const void* dskip, int lddskip, void* dx,
+                           int lddx, int dtype, int N, int H, int W, int C, mau_stream_t stream);
 
 /* ---- bilinear resize, align_corners=True (src/model.py:111-121,219,243-246) ---- */
 /* dst[..., choff:choff+C] = resize(src (N,h,w,C)) to (H,W); other channels of dst untouched. */

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "mau_conv3x3_unpack_wgrad": (_i, [_p, _i, _p, _i, _i, _p]),
     "mau_reduce_rows_ws_elems": (_sz, [_i, _i]),
     "mau_reduce_rows_f64": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "mau_reduce_rows_f64_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     "mau_reduce_rows_f32": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "mau_bn_finalize_train": (_i, [_p, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
     "mau_bn_stats_ws_elems": (_sz, [_i, _i]),
@@ -53,6 +54,7 @@ PROTOTYPES = {
     "mau_bn_bwd_rows": (_i, [_i64]),
     "mau_maxpool2x2_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_maxpool2x2_bwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_maxpool2x2_bwd_add": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_resize_bilinear_fwd": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mau_resize_bilinear_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_copy_channels": (_i, [_p, _i, _p, _i, _i, _i, _i, _i64, _i, _p]),

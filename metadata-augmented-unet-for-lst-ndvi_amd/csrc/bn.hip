@@ -16,7 +16,7 @@ namespace mau {
 // block = 64 columns x 4 row-lanes: each wave reads 64 consecutive columns of one row.
 template <typename InT, typename OutT>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const InT* __restrict__ slab, int rows, int M, int ldrow,
-                                                          OutT* __restrict__ out, int ldout) {
+                                                          OutT* __restrict__ out, int ldout, float* __restrict__ out32) {
   __shared__ double part[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
@@ -33,8 +33,11 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const InT* __restrict_
   }
   part[rl][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
-  if (rl == 0 && col < M)
-    out[(size_t)blockIdx.y * ldout + col] = (OutT)(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (rl == 0 && col < M) {
+    const double v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    out[(size_t)blockIdx.y * ldout + col] = (OutT)v;
+    if (out32 != nullptr) out32[col] = (float)v;         // (final level only) the same sums rounded to fp32
+  }
 }
 
 constexpr int REDUCE_MAX_CHUNKS = 128;
@@ -45,13 +48,15 @@ static int reduce_chunks(int rows) {
 }
 
 template <typename OutT>
-static int reduce_rows_launch(const float* slab, int rows, int M, int ldrow, OutT* out, double* ws, hipStream_t st) {
+static int reduce_rows_launch(const float* slab, int rows, int M, int ldrow, OutT* out, double* ws, hipStream_t st,
+                              float* out32 = nullptr) {
   const int chunks = reduce_chunks(rows);
+  float* const none = nullptr;
   if (chunks == 1 || ws == nullptr) {
-    MAU_LAUNCH((reduce_rows_kernel<float, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, slab, rows, M, ldrow, out, M);
+    MAU_LAUNCH((reduce_rows_kernel<float, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, slab, rows, M, ldrow, out, M, out32);
   } else {
-    MAU_LAUNCH((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, ldrow, ws, M);
-    MAU_LAUNCH((reduce_rows_kernel<double, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, (const double*)ws, chunks, M, M, out, M);
+    MAU_LAUNCH((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, ldrow, ws, M, none);
+    MAU_LAUNCH((reduce_rows_kernel<double, OutT>), dim3(ceil_div(M, 64), 1), dim3(256), 0, st, (const double*)ws, chunks, M, M, out, M, out32);
   }
   return check_launch("reduce_rows_kernel");
 }
@@ -337,6 +342,12 @@ int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* s
   return reduce_rows_launch<double>(slab, rows, M, ldrow, sums, ws, (hipStream_t)stream);
 }
 
+int mau_reduce_rows_f64_f32(const float* slab, int rows, int M, int ldrow, double* sums, float* sums32, double* ws,
+                            mau_stream_t stream) {
+  MAU_REQUIRE(slab && sums && sums32 && rows > 0 && M > 0 && ldrow >= M, "reduce_rows: bad arguments");
+  return reduce_rows_launch<double>(slab, rows, M, ldrow, sums, ws, (hipStream_t)stream, sums32);
+}
+
 int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, double* ws, mau_stream_t stream) {
   MAU_REQUIRE(slab && out && rows > 0 && M > 0 && ldrow >= M, "reduce_rows: bad arguments");
   return reduce_rows_launch<float>(slab, rows, M, ldrow, out, ws, (hipStream_t)stream);
@@ -362,7 +373,7 @@ int mau_bn_stats_finalize_train(const float* slab, int rows, double count, const
   hipStream_t st = (hipStream_t)stream;
   const int cpad = round_up(C, 64), M = 2 * cpad, chunks = reduce_chunks(rows);
   // level 1: the conv epilogue's slab [rows][2*cpad] -> fp64 partials [chunks][2*cpad]
-  MAU_LAUNCH((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, M, ws, M);
+  MAU_LAUNCH((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, M, ws, M, (float*)nullptr);
   // level 2 + finalize
   MAU_LAUNCH(bn_finalize_from_partials_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)ws, chunks, cpad, count, gamma,
              beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd, C);

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 // (0,0),(0,1),(1,0),(1,1) with strict '>' as ATen's max_pool2d), uncovered odd rows/cols get 0.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                          const T* __restrict__ dskip, int lddskip,
                                                           T* __restrict__ dx, int lddx, int H, int W, int C8) {
   const int Ho = H / 2, Wo = W / 2, nv = C8 >> 3;
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -134,6 +135,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
       if (v11.v[j] > m) { m = v11.v[j]; arg = 3; }
       o.v[j] = (arg == me) ? g.v[j] : 0.f;
     }
+  }
+  if (dskip != nullptr) {        // the other consumer of x (a skip connection): its gradient is added in the same pass
+    const F8 sk = load8<T>(dskip + (((size_t)n * H + yi) * W + xi) * lddskip + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] += sk.v[j];
   }
   store8<T>(dx + (((size_t)n * H + yi) * W + xi) * lddx + c, o);
 }
@@ -402,7 +408,21 @@ int mau_maxpool2x2_bwd(const void* x, int ldx, const void* dy, int lddy, void* d
   MAU_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ldx >= C8 && lddy >= C8 && lddx >= C8, "maxpool2x2_bwd: bad ld");
   MAU_REQUIRE(H <= 65535 && N <= 65535, "maxpool2x2_bwd: H and N must fit a grid dimension");
   dim3 grid(ceil_div(W * (C8 / 8), 256), H, N);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(maxpool_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, H, W, C8));
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(maxpool_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy,
+                                       (const T*)nullptr, 0, (T*)dx, lddx, H, W, C8));
+  return check_launch("maxpool_bwd_kernel");
+}
+
+int mau_maxpool2x2_bwd_add(const void* x, int ldx, const void* dy, int lddy, const void* dskip, int lddskip, void* dx, int lddx,
+                           int dtype, int N, int H, int W, int C, mau_stream_t stream) {
+  MAU_REQUIRE(x && dy && dskip && dx && N > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2x2_bwd_add: bad arguments");
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && lddskip % 8 == 0 && ldx >= C8 && lddy >= C8 && lddx >= C8 && lddskip >= C8,
+              "maxpool2x2_bwd_add: bad ld");
+  MAU_REQUIRE(H <= 65535 && N <= 65535, "maxpool2x2_bwd_add: H and N must fit a grid dimension");
+  dim3 grid(ceil_div(W * (C8 / 8), 256), H, N);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(maxpool_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy,
+                                       (const T*)dskip, lddskip, (T*)dx, lddx, H, W, C8));
   return check_launch("maxpool_bwd_kernel");
 }
 

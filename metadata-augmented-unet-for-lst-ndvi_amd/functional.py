@@ -266,9 +266,10 @@ class ConvBNReLU(torch.autograd.Function):
              mean.data_ptr(), invstd.data_ptr(), slab.data_ptr(), Cout, code, npix, Cout, stream)
         sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
         ws = torch.empty(lib.mau_reduce_rows_ws_elems(rows, 2 * Cout), dtype=torch.float64, device=dev)
-        call("mau_reduce_rows_f64", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), ws.data_ptr(), stream)
-        dgamma = sums[Cout:].float()
-        dbeta = sums[:Cout].float()
+        g32 = torch.empty(2 * Cout, **f32)                   # [dbeta | dgamma]: the LOCAL sums, rounded to fp32 by the reducer
+        call("mau_reduce_rows_f64_f32", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), g32.data_ptr(), ws.data_ptr(), stream)
+        dgamma = g32[Cout:]
+        dbeta = g32[:Cout]
         if st.training:
             _all_reduce_(sums, st)
             sums_apply, count = sums, float(npix * st.world)
@@ -343,6 +344,40 @@ class MaxPool2x2(torch.autograd.Function):
         dx = torch.empty((N, H, W, pad8(ctx.C)), dtype=x.dtype, device=x.device)
         call("mau_maxpool2x2_bwd", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), pad8(ctx.C),
              dtype_code(x.dtype), N, H, W, ctx.C, _stream())
+        return dx, None
+
+
+class PoolSkip(torch.autograd.Function):
+    """(maxpool2x2(x), x): an encoder activation feeds the next level through the pool AND the decoder through a skip
+    connection (src/model.py:268-271 with :279-282).  Autograd would add the two gradients of x in an extra pass over
+    the full-resolution tensor; here the skip gradient is added while the pool backward writes dx."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        x = _as_nhwc(x)
+        N, H, W, _ = x.shape
+        ldy = pad8(C)
+        y = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=x.device)
+        call("mau_maxpool2x2_fwd", x.data_ptr(), _ld(x), y.data_ptr(), ldy, dtype_code(x.dtype), N, H, W, C, _stream())
+        ctx.save_for_backward(x)
+        ctx.C = C
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        (x,) = ctx.saved_tensors
+        if dy is None:
+            return dskip, None
+        dy = _as_nhwc(dy)
+        N, H, W, _ = x.shape
+        dx = torch.empty((N, H, W, pad8(ctx.C)), dtype=x.dtype, device=x.device)
+        if dskip is None:
+            call("mau_maxpool2x2_bwd", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), pad8(ctx.C),
+                 dtype_code(x.dtype), N, H, W, ctx.C, _stream())
+        else:
+            dskip = _as_nhwc(dskip)
+            call("mau_maxpool2x2_bwd_add", x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dskip.data_ptr(), _ld(dskip),
+                 dx.data_ptr(), pad8(ctx.C), dtype_code(x.dtype), N, H, W, ctx.C, _stream())
         return dx, None
 
 

@@ -140,6 +140,13 @@ class _NetBase(nn.Module):
             return maps
         return Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
 
+    def _pool_skip(self, a: Act):
+        """(pool(a), a) for an encoder activation that also feeds a skip connection: one fused backward pass."""
+        if not (torch.is_grad_enabled() and a.t.requires_grad):
+            return self._pool(a), a
+        y, skip = F_.PoolSkip.apply(a.t, a.C)
+        return Act(y, a.C), Act(skip, a.C)
+
     def _pool(self, a: Act) -> Act:
         return Act(F_.MaxPool2x2.apply(a.t, a.C), a.C)
 
@@ -199,11 +206,10 @@ class UrbanPredictor_unet(_NetBase):
         temporal_emb = self.temporal_encoder(temp_series) if self.temporal_embeddings else None
         meta_emb = self.meta_encoder(metadata) if self.metadata_embeddings else None
         x = self._entry(maps)
-        x0_0 = self.conv0_0(x)
-        x1_0 = self.conv1_0(self._pool(x0_0))
-        x2_0 = self.conv2_0(self._pool(x1_0))
-        x3_0 = self.conv3_0(self._pool(x2_0))
-        x4_0 = self._pool(x3_0)
+        p, x0_0 = self._pool_skip(self.conv0_0(x))
+        p, x1_0 = self._pool_skip(self.conv1_0(p))
+        p, x2_0 = self._pool_skip(self.conv2_0(p))
+        x4_0, x3_0 = self._pool_skip(self.conv3_0(p))
         x4_0 = self._fused_block(self.conv4_0, x4_0, [e for e in (temporal_emb, meta_emb) if e is not None])
         x3_1 = self.conv3_1(self._up_cat(x3_0, x4_0))
         x2_1 = self.conv2_1(self._up_cat(x2_0, x3_1))
@@ -298,17 +304,17 @@ class UrbanPredictor_unetpp(_NetBase):
         meta_emb = self.meta_encoder(metadata)
         emb = torch.cat([temporal_emb, meta_emb], dim=1).float()           # src/model.py:103
         x = self._entry(maps)
-        x0_0 = self.conv0_0(x)
-        x1_0 = self.conv1_0(self._pool(x0_0))
+        p, x0_0 = self._pool_skip(self.conv0_0(x))          # (the skip copy feeds every node of the row)
+        p, x1_0 = self._pool_skip(self.conv1_0(p))
         x0_1 = self._node(self.conv0_1, [x0_0], x1_0, emb)
-        x2_0 = self.conv2_0(self._pool(x1_0))
+        p, x2_0 = self._pool_skip(self.conv2_0(p))
         x1_1 = self._node(self.conv1_1, [x1_0], x2_0, emb)
         x0_2 = self._node(self.conv0_2, [x0_0, x0_1], x1_1, emb)
-        x3_0 = self.conv3_0(self._pool(x2_0))
+        p, x3_0 = self._pool_skip(self.conv3_0(p))
         x2_1 = self._node(self.conv2_1, [x2_0], x3_0, emb)
         x1_2 = self._node(self.conv1_2, [x1_0, x1_1], x2_1, emb)
         x0_3 = self._node(self.conv0_3, [x0_0, x0_1, x0_2], x1_2, emb)
-        x4_0 = self.conv4_0(self._pool(x3_0))
+        x4_0 = self.conv4_0(p)
         x3_1 = self._node(self.conv3_1, [x3_0], x4_0, emb)
         x2_2 = self._node(self.conv2_2, [x2_0, x2_1], x3_1, emb)
         x1_3 = self._node(self.conv1_3, [x1_0, x1_1, x1_2], x2_2, emb)
