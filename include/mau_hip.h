@@ -77,9 +77,9 @@ size_t mau_conv3x3_packed_elems(int dtype, int nout, int nin);
  * pack `wd` [Cout/KC][9][Cin64][KC] (taps rotated by 180 degrees); either may be NULL, not both. */
 int mau_conv3x3_pack_weights(const float* w_oihw, void* wf, void* wd, int dtype, int Cout, int Cin,
                              mau_stream_t stream);
-/* Number of pixel tiles (= rows of the BatchNorm partial-statistics slab) the forward launch will use for an
- * N x H x W batch with Cout output channels (8x16-pixel tiles for MAU_F32; 16x16 / 32x16 / 64x16 for MAU_BF16,
- * chosen from Cout and H). */
+/* Rows of the BatchNorm partial-statistics slab the forward launch writes for an N x H x W batch with Cout output
+ * channels: one per 8x16-pixel tile for MAU_F32; one per (workgroup tile of 16x16 or 32x16 pixels, wave row) for
+ * MAU_BF16 -- the tile height is chosen per layer from how well its work items fill the 256 CUs. */
 int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout);
 /* y = conv3x3(cat([x, broadcast(emb)], C)) + bias.
  *   x     NHWC-ld with C0 channels;

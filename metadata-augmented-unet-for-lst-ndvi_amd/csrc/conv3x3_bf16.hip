@@ -22,6 +22,7 @@
 // Replaces nn.Conv2d(.,.,3,padding=1) + the statistics half of nn.BatchNorm2d of VGGBlock
 // (reference src/model.py:12-15).
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_common.h"
 
 namespace mau {
@@ -89,6 +90,31 @@ __device__ __forceinline__ void land(bf16x8 (&fb)[2], bf16x8 (&fa)[MT]) {
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]) : "n"(N));
 }
 
+// Epilogue staging through LDS, also from inline asm: for a compiler-visible LDS access that may alias an LDS-DMA
+// destination the waitcnt pass emits s_waitcnt vmcnt(0), which here would wait for the wave's OWN global stores
+// (stores count in vmcnt) -- one HBM write round trip per 128-byte row group, 37 % of a level-0 layer's time.
+template <int OFF>
+__device__ __forceinline__ void lds_write_b16(unsigned addr, unsigned v) {
+  asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_u128(unsigned addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+  return r;
+}
+__device__ __forceinline__ void lds_land(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // One (pixel tile, cout tile) work item.
 struct Item {
   int pixTile, n, ty0, tx0, co0;
@@ -117,8 +143,7 @@ struct Geo {
   static constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;       // every wave issues exactly PER_WAVE DMAs per stage:
   static constexpr int STAGE = PER_WAVE * NW * 1024;           // slots >= TOT_Q are padding fed from the zero page
   static_assert(PER_WAVE <= 9, "one DMA per tap");
-  static constexpr int RED_OFF = 2 * STAGE;
-  static constexpr size_t LDS = 2 * (size_t)STAGE + (size_t)WM * 2 * BN * sizeof(float);
+  static constexpr size_t LDS = 2 * (size_t)STAGE;
   static_assert(NW % WN == 0 && (size_t)NW * 32 * 64 * 2 <= STAGE, "epilogue staging must fit one stage buffer");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -261,7 +286,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
   issue(0, 0);
   int stage = 0;
   bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
-  float* red = reinterpret_cast<float*>(smem + G::RED_OFF);
 
   while (true) {
     const int In = next_valid(I + gridDim.x, nxt);
@@ -317,7 +341,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
 
     // ---- epilogue of `cur` (the next item's first stage is already in flight into buffer `stage`) ----
     __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer stage^1 -> reuse it
-    bf16* stg = reinterpret_cast<bf16*>(smem + (stage ^ 1) * STAGE) + wave * (32 * 64);   // wave-private 32 px x 64 ch
+    // wave-private staging image: 32 pixels x 64 channels bf16 (128-byte rows)
+    const unsigned stg = lds0 + (stage ^ 1) * STAGE + wave * (32 * 64 * 2);
+    unsigned wbase[4];                                 // write: row rowbase[g] + k, channel nt*32 + i32
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wbase[g] = stg + rowbase[g] * 128 + i32 * 2;
+    const unsigned rbase = stg + (lane >> 3) * 128 + (lane & 7) * 16;   // read: pixel pass*8 + lane/8, 16-byte vector lane%8
     float s[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
     float bv[2], psc[2] = {0.f, 0.f}, psh[2] = {0.f, 0.f};
 #pragma unroll
@@ -338,72 +367,52 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int ybase = cur.ty0 + wm * MT * 2 + mt * 2;
-      if (full) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              float v = acc[mt][nt][g * 4 + k] + bv[nt];
-              if (EPI == EPI_POST) v = fmaxf(fmaf(v, psc[nt], psh[nt]), 0.f);
-              if (EPI == EPI_STATS) {
-                s[nt] += v;
-                q2[nt] = fmaf(v, v, q2[nt]);
-              }
-              stg[(rowbase[g] + k) * 64 + nt * 32 + i32] = (bf16)v;
-            }
-      } else {
+      auto stage_rows = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const bool yok = ybase + (rowbase[g] >> 4) < p.H;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const bool ok = yok && k < xlim[g];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-              float v = acc[mt][nt][g * 4 + k] + bv[nt];
-              if (EPI == EPI_POST) v = fmaxf(fmaf(v, psc[nt], psh[nt]), 0.f);
-              if (EPI == EPI_STATS && ok) {
-                s[nt] += v;
-                q2[nt] = fmaf(v, v, q2[nt]);
-              }
-              stg[(rowbase[g] + k) * 64 + nt * 32 + i32] = (bf16)v;
+          const bool yok = FULL || ybase + (rowbase[g] >> 4) < p.H;
+          static_for<0, 8>([&](auto ic) {
+            constexpr int k = decltype(ic)::value >> 1, nt = decltype(ic)::value & 1;
+            float v = acc[mt][nt][g * 4 + k] + bv[nt];
+            if (EPI == EPI_POST) v = fmaxf(fmaf(v, psc[nt], psh[nt]), 0.f);
+            if (EPI == EPI_STATS && (FULL || (yok && k < xlim[g]))) {
+              s[nt] += v;
+              q2[nt] = fmaf(v, v, q2[nt]);
             }
-          }
+            lds_write_b16<k * 128 + nt * 64>(wbase[g], (unsigned)__builtin_bit_cast(unsigned short, (bf16)v));
+          });
         }
-      }
-      // whole 128-byte rows: lane (pixel = pass*8 + lane/8, 16-byte vector = lane%8); wave-private LDS,
-      // DS operations of one wave execute in order -> no barrier needed between the writes and these reads
+      };
+      if (full) stage_rows(std::true_type{});
+      else stage_rows(std::false_type{});
+      // whole 128-byte rows leave as 16-byte vectors.  DS operations of one wave execute in order, so the reads
+      // follow the writes without a barrier; the four global stores are issued back to back, nothing waits for them.
+      u32x4 o0 = lds_read_u128<0 * 1024>(rbase), o1 = lds_read_u128<1 * 1024>(rbase);
+      u32x4 o2 = lds_read_u128<2 * 1024>(rbase), o3 = lds_read_u128<3 * 1024>(rbase);
+      lds_land(o0, o1, o2, o3);
       if (cv < p.ldy) {
+        const u32x4 ov[4] = {o0, o1, o2, o3};
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
           const int prow = pass * 8 + (lane >> 3);
           const int gy = ybase + (prow >> 4), gx = cur.tx0 + (prow & 15);
-          if (full || (gy < p.H && gx < p.W)) {
-            const uint4 v = *reinterpret_cast<const uint4*>(stg + prow * 64 + (lane & 7) * 8);
-            *reinterpret_cast<uint4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv) = v;
-          }
+          if (full || (gy < p.H && gx < p.W))
+            *reinterpret_cast<u32x4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv) = ov[pass];
         }
       }
     }
     if (EPI == EPI_STATS) {
+      // one slab row per (pixel tile, wave row): no cross-wave reduction, hence no barrier and no LDS round trip here
+      float* srow = p.slab + ((size_t)cur.pixTile * WM + wm) * 2 * p.CoutPad + cur.co0 + wn * 64 + i32;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         s[nt] += __shfl_xor(s[nt], 32);
         q2[nt] += __shfl_xor(q2[nt], 32);
         if (h == 0) {
-          red[(wm * 2 + 0) * BN + wn * 64 + nt * 32 + i32] = s[nt];
-          red[(wm * 2 + 1) * BN + wn * 64 + nt * 32 + i32] = q2[nt];
+          srow[nt * 32] = s[nt];
+          srow[p.CoutPad + nt * 32] = q2[nt];
         }
-      }
-      __syncthreads();                                 // (may also drain the next item's first DMA: harmless)
-      if (tid < 2 * BN) {
-        const int which = tid / BN, c = tid % BN;
-        float v = 0.f;
-#pragma unroll
-        for (int m = 0; m < WM; ++m) v += red[(m * 2 + which) * BN + c];
-        p.slab[((size_t)cur.pixTile * 2 + which) * p.CoutPad + cur.co0 + c] = v;
       }
     }
     if (In < 0) break;
@@ -463,8 +472,13 @@ static inline int tile_height(int CoutPad, int N, int H, int W) {
 }
 }  // namespace v2
 
+// rows of the BatchNorm partial-sum slab: one per (pixel tile, wave row of the workgroup)
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
-  return N * ceil_div(H, v2::tile_height(round_up(Cout, 64), N, H, W)) * ceil_div(W, v2::TW);
+  const int CoutPad = round_up(Cout, 64);
+  const int th = v2::tile_height(CoutPad, N, H, W);
+  const int wm = (CoutPad % 128 != 0 && th == 32) ? v2::Geo<64, 2, 8>::WM : 4;     // <128,2,8>, <128,4,8>, <64,2,4>: WM = 4
+  static_assert(v2::Geo<128, 2, 8>::WM == 4 && v2::Geo<128, 4, 8>::WM == 4 && v2::Geo<64, 2, 4>::WM == 4, "slab rows");
+  return wm * N * ceil_div(H, th) * ceil_div(W, v2::TW);
 }
 
 template <int BN, int MT, int NW>
