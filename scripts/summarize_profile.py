@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of scripts/profile.sh (gpurun_out/prof_<tag>/) into the committed summaries:
+   profiles/<round>/kernel_stats_bench_steps3.csv, pmc_per_kernel.csv, dominant_kernel_summary.json
+Usage: scripts/summarize_profile.py gpurun_out/prof_<tag> profiles/r1"""
+import collections, csv, glob, json, os, shutil, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
+shutil.copy(stats, os.path.join(dst, "kernel_stats_bench_steps3.csv"))
+rows = list(csv.DictReader(open(stats)))
+total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(lambda: collections.defaultdict(set))
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k, c = r["Kernel_Name"], r["Counter_Name"]
+        agg[k][c] += float(r["Counter_Value"])
+        disp[k][c].add(r["Dispatch_Id"])
+with open(os.path.join(dst, "pmc_per_kernel.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "counter", "dispatches", "sum", "per_dispatch"])
+    for k in sorted(agg):
+        for c in sorted(agg[k]):
+            n = len(disp[k][c])
+            w.writerow([k, c, n, f"{agg[k][c]:.6g}", f"{agg[k][c] / max(n, 1):.6g}"])
+
+
+def family(pred):
+    sel = [r for r in rows if pred(r["Name"])]
+    calls = sum(int(r["Calls"]) for r in sel)
+    ns = sum(float(r["TotalDurationNs"]) for r in sel)
+    cnt = collections.defaultdict(float)
+    nd = 0
+    for k in agg:
+        if pred(k):
+            for c, v in agg[k].items():
+                cnt[c] += v
+            nd += len(disp[k].get("FETCH_SIZE", ()))
+    out = {"launches": calls, "avg_launch_us_rocprof": ns / max(calls, 1) / 1e3, "share_of_kernel_time": ns / total_ns, "pmc_dispatches": nd}
+    if nd:
+        out["hbm_bytes_per_launch_pmc"] = (2 * cnt["FETCH_SIZE"] + cnt["WRITE_SIZE"]) * 1024 / nd
+    if cnt.get("GRBM_GUI_ACTIVE"):
+        out["mfma_busy_fraction"] = cnt["SQ_VALU_MFMA_BUSY_CYCLES"] / (cnt["GRBM_GUI_ACTIVE"] / 8 * 256 * 4)
+    if cnt.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_bank_conflict_fraction"] = cnt["SQ_LDS_BANK_CONFLICT"] / cnt["SQ_LDS_IDX_ACTIVE"]
+    if cnt.get("TCC_HIT_sum"):
+        out["l2_hit_rate"] = cnt["TCC_HIT_sum"] / (cnt["TCC_HIT_sum"] + cnt["TCC_MISS_sum"])
+    return out
+
+
+summary = {
+    "command": "rocprofv3 --kernel-trace [--stats | --pmc <set>] --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   (4 train steps + 7 eval forwards; scripts/profile.sh, scripts/summarize_profile.py)",
+    "correction": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced reads incl. LDS-DMA; WRITE_SIZE is exact for 16-B stores (MI355X_MICROARCH.md, HBM section)",
+    "mfma_busy_fraction": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs)",
+    "conv3x3_bf16_kernel (dominant: forward + data gradient)": family(lambda n: "conv3x3_bf16_kernel" in n),
+    "wgrad_bf16_kernel": family(lambda n: "wgrad_bf16_kernel" in n),
+}
+json.dump(summary, open(os.path.join(dst, "dominant_kernel_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
+top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:12]
+for r in top:
+    print(f"{r['Name'][:80]:80s} {int(r['Calls']):5d} {float(r['TotalDurationNs']) / total_ns * 100:5.1f}%")
