@@ -398,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
           const int prow = pass * 8 + (lane >> 3);
           const int gy = ybase + (prow >> 4), gx = cur.tx0 + (prow & 15);
           if (full || (gy < p.H && gx < p.W))
-            *reinterpret_cast<u32x4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv) = ov[pass];
+            __builtin_nontemporal_store(ov[pass], reinterpret_cast<u32x4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv));
         }
       }
     }
