@@ -87,20 +87,37 @@ __global__ void bn_finalize_train_kernel(const double* __restrict__ sums, double
 
 // Fused second level of the statistics reduce + finalize (single-GPU training): partial fp64 sums
 // [chunks][2*ldp] (column c: sum, column ldp + c: sum of squares) -> the same outputs as
-// bn_finalize_train_kernel.  One thread per channel, chunks added in fixed order.
-__global__ void bn_finalize_from_partials_kernel(const double* __restrict__ part, int chunks, int ldp, double count,
+// bn_finalize_train_kernel; chunks added in a fixed order (bitwise reproducible).
+// block = 64 channels x 4 chunk-lanes: each lane adds every 4th chunk (two independent chains), LDS joins the four.
+__global__ __launch_bounds__(256) void bn_finalize_from_partials_kernel(const double* __restrict__ part, int chunks, int ldp, double count,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                  float* __restrict__ rmean, float* __restrict__ rvar, int64_t* nbt, float momentum,
                                                  float eps, float* __restrict__ scale, float* __restrict__ shift,
                                                  float* __restrict__ mean_o, float* __restrict__ invstd_o, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < chunks; ++k) {
-    s += part[(size_t)k * 2 * ldp + c];
-    q += part[(size_t)k * 2 * ldp + ldp + c];
+  __shared__ double ps[4][64], pq[4][64];
+  const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+  if (c < C) {
+    int k = kl;
+    for (; k + 4 < chunks; k += 8) {
+      s0 += part[(size_t)k * 2 * ldp + c];
+      q0 += part[(size_t)k * 2 * ldp + ldp + c];
+      s1 += part[(size_t)(k + 4) * 2 * ldp + c];
+      q1 += part[(size_t)(k + 4) * 2 * ldp + ldp + c];
+    }
+    if (k < chunks) {
+      s0 += part[(size_t)k * 2 * ldp + c];
+      q0 += part[(size_t)k * 2 * ldp + ldp + c];
+    }
   }
+  ps[kl][cl] = s0 + s1;
+  pq[kl][cl] = q0 + q1;
+  __syncthreads();
+  if (kl != 0 || c >= C) return;
+  const double s = (ps[0][cl] + ps[1][cl]) + (ps[2][cl] + ps[3][cl]);
+  const double q = (pq[0][cl] + pq[1][cl]) + (pq[2][cl] + pq[3][cl]);
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -375,7 +392,7 @@ int mau_bn_stats_finalize_train(const float* slab, int rows, double count, const
   // level 1: the conv epilogue's slab [rows][2*cpad] -> fp64 partials [chunks][2*cpad]
   MAU_LAUNCH((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, M, ws, M, (float*)nullptr);
   // level 2 + finalize
-  MAU_LAUNCH(bn_finalize_from_partials_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const double*)ws, chunks, cpad, count, gamma,
+  MAU_LAUNCH(bn_finalize_from_partials_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, (const double*)ws, chunks, cpad, count, gamma,
              beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd, C);
   return check_launch("bn_stats_finalize_train");
 }
