@@ -162,11 +162,11 @@ struct PixVec {
 };
 // pixels per workgroup: 8..32 pixels per thread (the per-channel coefficient set-up is amortised over
 // them) while keeping at least ~2048 workgroups in flight for the chip
-static inline int pixvec_pixels_per_block(int nv, int64_t npix, int max_per_thread) {
+static inline int pixvec_pixels_per_block(int nv, int64_t npix, int max_per_thread, int min_blocks = 2048) {
   const int nvl = nv < 256 ? nv : 256;
   const int ps = 256 / nvl;
   int per_thread = max_per_thread;
-  while (per_thread > 8 && npix / ((int64_t)ps * per_thread) < 2048) per_thread >>= 1;
+  while (per_thread > 8 && npix / ((int64_t)ps * per_thread) < min_blocks) per_thread >>= 1;
   return ps * per_thread;
 }
 
@@ -410,7 +410,10 @@ int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* s
   MAU_REQUIRE(y && a && scale && shift && npix > 0 && C > 0, "bn_relu_apply: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && lda % 8 == 0 && ldy >= C8 && lda >= C8, "bn_relu_apply: bad ld");
-  const int pixb = pixvec_pixels_per_block(C8 / 8, npix, 8);
+  // measured (scripts/elementwise_bench.py): the 2M-pixel level-0 tensors stream best with many short workgroups,
+  // the smaller ones with few long ones (the per-channel coefficient set-up is paid once per thread)
+  const bool big = npix >= (int64_t)1 << 20;
+  const int pixb = pixvec_pixels_per_block(C8 / 8, npix, big ? 8 : 32, big ? 2048 : 256);
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bn_relu_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)y, ldy, scale, shift, (T*)a, lda, npix, C, C8, pixb));
   return check_launch("bn_relu_apply_kernel");
@@ -436,7 +439,9 @@ int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, cons
   MAU_REQUIRE(da && y && dy && sums && npix > 0 && C > 0 && count > 0, "bn_relu_bwd_apply: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && lddy >= C8, "bn_relu_bwd_apply: bad ld");
-  const int pixb = pixvec_pixels_per_block(C8 / 8, npix, 32);
+  // up to 64 pixels per thread and as few as 256 workgroups: this kernel's per-channel set-up (6 coefficient vectors,
+  // fp64 means) is what the mid-size layers were paying for (C=256: 61 -> 36 us, scripts/elementwise_bench.py)
+  const int pixb = pixvec_pixels_per_block(C8 / 8, npix, 64, 256);
   static const bool nt = getenv("MAU_BN_NT") ? atoi(getenv("MAU_BN_NT")) != 0 : false;
   if (nt) {
     MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((bn_relu_bwd_apply_kernel<T, true>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
