@@ -10,7 +10,8 @@ Two collectives per step family:
     reverse registration order (= backward arrival order) and each bucket is all-reduced
     asynchronously as soon as its last gradient has arrived, overlapping the rest of backward.
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages (default 32 MiB) keep
-    every link busy; tiny per-tensor messages would be latency-bound.
+    every link busy; tiny per-tensor messages would be latency-bound.  A bucket's gradients enter the
+    arena through one multi-tensor copy and are averaged by the collective (ReduceOp.AVG on RCCL).
   * BatchNorm: per layer one all-reduce of [sum | sum of squares] (2C fp64) in forward and one of
     [sum dz | sum dz*xhat] in backward -- see ``functional.ConvBNReLU``; enabled by
     ``model.set_sync_bn(group)``.
@@ -84,6 +85,7 @@ class GradSync:
             self.buckets.append(cur)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._active = False
+        self._avg = self.group is not None and dist.get_backend(self.group) == "nccl"
 
     # ------------------------------------------------------------------ #
     def begin(self):
@@ -94,18 +96,27 @@ class GradSync:
         self._active = True
 
     def _launch(self, b: _Bucket):
+        """All gradients of the bucket have arrived: move them into the arena with ONE multi-tensor copy (instead of a
+        small kernel per parameter), re-point ``p.grad`` at the arena slots, start the bucket's all-reduce."""
         b.launched = True
+        have = [p for p in b.params if p.grad is not None]
+        if have:
+            views = [self.flat[self._slot[id(p)][0]:self._slot[id(p)][1]].view_as(p) for p in have]
+            torch._foreach_copy_(views, [p.grad for p in have])
+            for p, v in zip(have, views):
+                p.grad = v
         if self.group is not None:
-            b.handle = all_reduce_sum(self.flat[b.lo:b.hi], self.group, async_op=True)
+            seg = self.flat[b.lo:b.hi]
+            if self._avg:                                  # RCCL averages in the collective itself
+                b.handle = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            else:                                          # gloo has no AVG: pre-scale, then SUM
+                seg.mul_(1.0 / self.world)
+                b.handle = all_reduce_sum(seg, self.group, async_op=True)
 
     def _on_grad(self, p: torch.nn.Parameter):
         if not self._active:
             return
-        lo, hi, b = self._slot[id(p)]
-        view = self.flat[lo:hi].view_as(p)
-        # pre-scale so that the SUM all-reduce yields the mean (gloo has no AVG)
-        torch.mul(p.grad, 1.0 / self.world, out=view)
-        p.grad = view
+        b = self._slot[id(p)][2]
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
