@@ -38,7 +38,6 @@ __device__ __forceinline__ int swz256(int row) { return (row & 3) << 2; }       
 __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lo, int hi_delta) {
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(lo));
   const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(lo + hi_delta));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
