@@ -63,7 +63,10 @@ def _exact_int_case(g, N, Cin, Cout, H, W):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (1, 8, 64, 31, 17),
                                    (1, 3, 5, 2, 3), (4, 8, 8, 3, 3), (2, 17, 70, 5, 40), (1, 64, 64, 16, 16), (9, 1, 1, 1, 1),
-                                   (3, 200, 72, 20, 34)])
+                                   (3, 200, 72, 20, 34),
+                                   # more work items than persistent workgroups (several items per workgroup, cross-item
+                                   # prefetch), 32-row tiles with ragged bottom/right edges, 1-chunk K loops, 2-3 cout tiles
+                                   (6, 24, 130, 70, 100), (8, 64, 256, 96, 112), (12, 6, 64, 100, 100), (3, 40, 128, 33, 17)])
 def test_conv3x3_exact_integers(mau, dt, shape):
     """Small-integer data is exact in bf16 and fp32: the MFMA operand/accumulator lane maps, halo
     handling and edge masking must reproduce torch's conv2d bit for bit (asymmetric weights)."""
@@ -100,7 +103,8 @@ def test_conv3x3_exact_integers(mau, dt, shape):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (3, 64, 128, 24, 40),
-                                   (2, 136, 256, 16, 16), (1, 3, 5, 2, 3), (4, 8, 8, 3, 3), (9, 1, 1, 1, 1), (2, 17, 70, 5, 40)])
+                                   (2, 136, 256, 16, 16), (1, 3, 5, 2, 3), (4, 8, 8, 3, 3), (9, 1, 1, 1, 1), (2, 17, 70, 5, 40),
+                                   (6, 24, 130, 70, 100), (8, 64, 256, 96, 112), (3, 40, 128, 33, 17)])
 def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
     from mau_amd import functional as F_
     from mau_amd._lib import call, lib
