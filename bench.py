@@ -203,6 +203,7 @@ def main():
     if rank != 0:
         if world > 1:
             dist.barrier()
+            dist.destroy_process_group()
         return
 
     conv = timer.summary()
@@ -248,6 +249,7 @@ def main():
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
