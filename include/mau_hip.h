@@ -74,7 +74,8 @@ int mau_conv3x3_kc(int dtype);
 /* Elements (of `dtype`) of a packed weight buffer with `nout` output and `nin` input channels. */
 size_t mau_conv3x3_packed_elems(int dtype, int nout, int nin);
 /* OIHW fp32 weights (Cout,Cin,3,3) -> forward pack `wf` [Cin/KC][9][Cout64][KC] and/or data-gradient
- * pack `wd` [Cout/KC][9][Cin64][KC] (taps rotated by 180 degrees); either may be NULL, not both. */
+ * pack `wd` [Cout/KC][9][Cin64][KC] (taps rotated by 180 degrees); either may be NULL, not both.  The packs are opaque
+ * inputs of mau_conv3x3_fwd for the same dtype (MAU_BF16 permutes the rows inside every 64-row block). */
 int mau_conv3x3_pack_weights(const float* w_oihw, void* wf, void* wd, int dtype, int Cout, int Cin,
                              mau_stream_t stream);
 /* Rows of the BatchNorm partial-statistics slab the forward launch writes for an N x H x W batch with Cout output

@@ -327,6 +327,14 @@ __global__ __launch_bounds__(NT) void conv3x3_wgrad_kernel(WgradP p) {
 // ------------------------------------------------------------------------------------------
 // weight packing / gradient unpacking
 // ------------------------------------------------------------------------------------------
+// bf16 packs: position q of every 64-row block of the "output" dimension holds channel 2*(q & 31) + (q >> 5), so that
+// the two 32-column accumulator tiles of an MFMA lane carry ADJACENT channels (the bf16 kernel's epilogue converts and
+// stores them as one pair); the fp32 parity kernels keep the natural order.
+template <typename T>
+__device__ __forceinline__ int pack_row_channel(int q) {
+  return sizeof(T) == 2 ? (q & ~63) + 2 * (q & 31) + ((q >> 5) & 1) : q;
+}
+
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
                                     int Cout, int Cin) {
@@ -340,7 +348,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
       size_t t = idx;
       const int kc = t % KC;
       t /= KC;
-      const int co = t % CoutPad;
+      const int co = pack_row_channel<T>((int)(t % CoutPad));
       t /= CoutPad;
       const int tap = t % 9;
       const int ci = (int)(t / 9) * KC + kc;
@@ -351,7 +359,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
       size_t t = idx - nF;
       const int kc = t % KC;
       t /= KC;
-      const int ci = t % CinPad;
+      const int ci = pack_row_channel<T>((int)(t % CinPad));
       t /= CinPad;
       const int tap = t % 9;
       const int co = (int)(t / 9) * KC + kc;

@@ -183,6 +183,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
         }
       } else if (q < TOT_Q) {
         const int row = slot_hp[j];
+        // (the packed rows are pre-permuted: row nt*32 + i of a 64-channel block holds output channel 2*i + nt, so the
+        // two accumulator tiles of a lane carry ADJACENT channels -- pack_weights_kernel, conv3x3.hip)
         const int tap = row / BN, co = row % BN;
         src_base[j] = wg + ((size_t)tap * p.CoutPad + it.co0 + co) * KC + slot_c[j];
       }
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;   // (bias-initialised accumulators make the MT = 4 variants spill 100 registers)
 
     // ---- K loop.  Per stage: wait for this wave's DMAs -> raw barrier (every wave's DMAs have landed and
     // everyone is done with the buffer that is refilled next) -> issue the following stage, which may
@@ -286,19 +288,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer stage^1 -> reuse it
     // wave-private staging image: 32 pixels x 64 channels bf16 (128-byte rows)
     const unsigned stg = lds0 + (stage ^ 1) * STAGE + wave * (32 * 64 * 2);
-    unsigned wbase[4];                                 // write: row rowbase[g] + k, channel nt*32 + i32
+    unsigned wbase[4];                                 // write: row rowbase[g] + k, channel pair 2*i32 (one dword)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) wbase[g] = stg + rowbase[g] * 128 + i32 * 2;
+    for (int g = 0; g < 4; ++g) wbase[g] = stg + rowbase[g] * 128 + i32 * 4;
     const unsigned rbase = stg + (lane >> 3) * 128 + (lane & 7) * 16;   // read: pixel pass*8 + lane/8, 16-byte vector lane%8
-    float s[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};
-    float bv[2], psc[2] = {0.f, 0.f}, psh[2] = {0.f, 0.f};
+    // lane i32, accumulator tile nt <-> output channel 2*i32 + nt of the wave's 64 (see pack_weights_kernel)
+    const int cpair = cur.co0 + wn * 64 + 2 * i32;
+    float bv[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int co = cur.co0 + wn * 64 + nt * 32 + i32;
-      bv[nt] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
-      if (EPI == EPI_POST) {
-        psc[nt] = co < p.Cout ? p.post_scale[co] : 0.f;
-        psh[nt] = co < p.Cout ? p.post_shift[co] : 0.f;
+    for (int nt = 0; nt < 2; ++nt) bv[nt] = (p.bias != nullptr && cpair + nt < p.Cout) ? p.bias[cpair + nt] : 0.f;
+    float s[2] = {0.f, 0.f}, q2[2] = {0.f, 0.f};      // statistics of the channel pair
+    float psc[2] = {0.f, 0.f}, psh[2] = {0.f, 0.f};
+    if (EPI == EPI_POST) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        psc[nt] = cpair + nt < p.Cout ? p.post_scale[cpair + nt] : 0.f;
+        psh[nt] = cpair + nt < p.Cout ? p.post_shift[cpair + nt] : 0.f;
       }
     }
     const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
@@ -315,15 +320,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const bool yok = FULL || ybase + (rowbase[g] >> 4) < p.H;
-          static_for<0, 8>([&](auto ic) {
-            constexpr int k = decltype(ic)::value >> 1, nt = decltype(ic)::value & 1;
-            float v = acc[mt][nt][g * 4 + k] + bv[nt];
-            if (EPI == EPI_POST) v = fmaxf(fmaf(v, psc[nt], psh[nt]), 0.f);
-            if (EPI == EPI_STATS && (FULL || (yok && k < xlim[g]))) {
-              s[nt] += v;
-              q2[nt] = fmaf(v, v, q2[nt]);
+          static_for<0, 4>([&](auto ic) {
+            constexpr int k = decltype(ic)::value;
+            // (scalar f32 math on purpose: packed v_pk_* needs the pair in adjacent registers, which made the
+            //  128-accumulator variants spill 100 more registers)
+            float v0 = acc[mt][0][g * 4 + k] + bv[0], v1 = acc[mt][1][g * 4 + k] + bv[1];
+            if (EPI == EPI_POST) {
+              v0 = fmaxf(fmaf(v0, psc[0], psh[0]), 0.f);
+              v1 = fmaxf(fmaf(v1, psc[1], psh[1]), 0.f);
             }
-            lds_write_b16<k * 128 + nt * 64>(wbase[g], (unsigned)__builtin_bit_cast(unsigned short, (bf16)v));
+            if (EPI == EPI_STATS && (FULL || (yok && k < xlim[g]))) {
+              s[0] += v0;
+              s[1] += v1;
+              q2[0] = fmaf(v0, v0, q2[0]);
+              q2[1] = fmaf(v1, v1, q2[1]);
+            }
+            const f32x2 v = {v0, v1};
+            lds_write_b32<k * 128>(wbase[g], pack_bf16x2(v));
           });
         }
       };
@@ -347,15 +360,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     }
     if (EPI == EPI_STATS) {
       // one slab row per (pixel tile, wave row): no cross-wave reduction, hence no barrier and no LDS round trip here
-      float* srow = p.slab + ((size_t)cur.pixTile * WM + wm) * 2 * p.CoutPad + cur.co0 + wn * 64 + i32;
+      float* srow = p.slab + ((size_t)cur.pixTile * WM + wm) * 2 * p.CoutPad + cpair;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         s[nt] += __shfl_xor(s[nt], 32);
         q2[nt] += __shfl_xor(q2[nt], 32);
-        if (h == 0) {
-          srow[nt * 32] = s[nt];
-          srow[p.CoutPad + nt * 32] = q2[nt];
-        }
+      }
+      if (h == 0) {
+        const f32x2 sv = {s[0], s[1]}, qv = {q2[0], q2[1]};
+        *reinterpret_cast<f32x2*>(srow) = sv;
+        *reinterpret_cast<f32x2*>(srow + p.CoutPad) = qv;
       }
     }
     if (In < 0) break;

@@ -41,6 +41,14 @@ template <int OFF>
 __device__ __forceinline__ void lds_write_b16(unsigned addr, unsigned v) {
   asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void lds_write_b32(unsigned addr, unsigned v) {
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> one dword of two bf16 (round to nearest even): v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16x2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int OFF>
 __device__ __forceinline__ u32x4 lds_read_u128(unsigned addr) {
