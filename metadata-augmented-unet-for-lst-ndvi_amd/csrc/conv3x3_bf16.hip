@@ -315,8 +315,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int ybase = cur.ty0 + wm * MT * 2 + mt * 2;
-      auto stage_rows = [&](auto fullc) {
-        constexpr bool FULL = decltype(fullc)::value;
+      auto stage_rows = [&](auto fullc, auto biasc) {
+        constexpr bool FULL = decltype(fullc)::value, BIAS = decltype(biasc)::value;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const bool yok = FULL || ybase + (rowbase[g] >> 4) < p.H;
@@ -324,7 +324,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
             constexpr int k = decltype(ic)::value;
             // (scalar f32 math on purpose: packed v_pk_* needs the pair in adjacent registers, which made the
             //  128-accumulator variants spill 100 more registers)
-            float v0 = acc[mt][0][g * 4 + k] + bv[0], v1 = acc[mt][1][g * 4 + k] + bv[1];
+            float v0 = acc[mt][0][g * 4 + k], v1 = acc[mt][1][g * 4 + k];
+            if (BIAS) {
+              v0 += bv[0];
+              v1 += bv[1];
+            }
             if (EPI == EPI_POST) {
               v0 = fmaxf(fmaf(v0, psc[0], psh[0]), 0.f);
               v1 = fmaxf(fmaf(v1, psc[1], psh[1]), 0.f);
@@ -340,8 +344,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
           });
         }
       };
-      if (full) stage_rows(std::true_type{});
-      else stage_rows(std::false_type{});
+      if (p.bias != nullptr) {                         // (workgroup-uniform; the data gradient has no bias to add)
+        if (full) stage_rows(std::true_type{}, std::true_type{});
+        else stage_rows(std::false_type{}, std::true_type{});
+      } else {
+        if (full) stage_rows(std::true_type{}, std::false_type{});
+        else stage_rows(std::false_type{}, std::false_type{});
+      }
       // whole 128-byte rows leave as 16-byte vectors.  DS operations of one wave execute in order, so the reads
       // follow the writes without a barrier; the four global stores are issued back to back, nothing waits for them.
       u32x4 o0 = lds_read_u128<0 * 1024>(rbase), o1 = lds_read_u128<1 * 1024>(rbase);
