@@ -162,7 +162,7 @@ def main():
         losses[i] = loss.detach()
 
     if args.infer:
-        net.eval()
+        net.eval().freeze_inference()      # inference session: packed weights / folded BN coefficients computed once
     timer = ConvTimer(F_)
     timer.install()
 

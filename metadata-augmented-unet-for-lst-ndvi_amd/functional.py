@@ -154,6 +154,7 @@ class BNState:
     group: object = None                  # torch.distributed process group for SyncBN (None = local BN)
     world: int = 1
     grad_enabled: bool = True             # torch.is_grad_enabled() at call time (invisible inside Function.forward)
+    frozen: object = None                 # dict of a frozen inference session (packed weights, scale, shift) or None
 
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
@@ -192,6 +193,22 @@ class ConvBNReLU(torch.autograd.Function):
         ldx = _ld(x)
         ldy = pad8(Cout)
         stream = _stream()
+        inference = (not st.training) and (not st.grad_enabled or not any(ctx.needs_input_grad))
+        if inference and st.frozen is not None:
+            # frozen session (UrbanPredictor.freeze_inference): the packed weights and the folded BatchNorm coefficients
+            # were computed once; per call only the convolution itself runs
+            fz = st.frozen
+            if "wf" not in fz or fz["wf"].dtype != x.dtype:
+                fz["wf"] = pack_conv_weights(weight, code, forward=True, dgrad=False)[0]
+                fz["scale"], fz["shift"] = torch.empty(Cout, dtype=torch.float32, device=dev), torch.empty(Cout, dtype=torch.float32, device=dev)
+                call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
+                     st.eps, fz["scale"].data_ptr(), fz["shift"].data_ptr(), None, None, Cout, stream)
+            y = torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
+            emb_ws = torch.empty((N, E), dtype=x.dtype, device=dev) if E else None
+            call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,
+                 emb_ws.data_ptr() if E else None, E, fz["wf"].data_ptr(), bias.data_ptr(), fz["scale"].data_ptr(),
+                 fz["shift"].data_ptr(), y.data_ptr(), ldy, Cout, None, code, N, H, W, stream)
+            return y
         need_dgrad_pack = st.grad_enabled and (ctx.needs_input_grad[0] or (E > 0 and ctx.needs_input_grad[1]))
         wf, wd = pack_conv_weights(weight, code, forward=True, dgrad=need_dgrad_pack)
         y = torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)

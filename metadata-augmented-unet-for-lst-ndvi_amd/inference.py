@@ -15,7 +15,8 @@ class GraphedInference:
     """``GraphedInference(model, maps, temp_series, metadata)(maps, temp_series, metadata) -> output``.
 
     The example inputs fix shapes/dtypes; later calls may pass different VALUES of the same shapes.
-    The model's weights are read at replay time through the packed copies made during warm-up, so
+    The session freezes the model (``freeze_inference``): packed weights and folded BatchNorm coefficients are
+    computed once during warm-up and the captured graph holds only the per-call kernels, so
     reload weights -> build a new session (cheap: a few forwards).
     """
 
@@ -24,6 +25,8 @@ class GraphedInference:
         if not maps.is_cuda:
             raise RuntimeError("GraphedInference needs inputs on the MI355X ('cuda') device; there is no CPU fallback")
         self.model = model.eval()
+        if hasattr(self.model, "freeze_inference"):
+            self.model.freeze_inference(True)           # packed weights / folded BN coefficients computed once, outside the graph
         self._in = [maps.detach().clone(), temp_series.detach().clone(), metadata.detach().clone()]
         side = torch.cuda.Stream(device=maps.device)
         side.wait_stream(torch.cuda.current_stream())

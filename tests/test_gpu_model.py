@@ -259,3 +259,29 @@ def test_metadata_sweep_reuses_encoder(mau, flags):
         net.forward_metadata_sweep(x, ts, md)
     with pytest.raises(NotImplementedError):
         mau.UrbanPredictor("unet++", 23, 12, 16, 8, 16, 24, 2, base_filters=8).cuda().eval().forward_metadata_sweep(x, ts, md)
+
+
+def test_frozen_inference_matches_and_unfreezes(mau):
+    """freeze_inference: same outputs with the packed weights / folded BN coefficients computed once; train(),
+    load_state_dict and set_precision drop the frozen copies so that later forwards see the new parameters."""
+    torch.manual_seed(11)
+    net = mau.UrbanPredictor("unet", 23, 12, 16, 8, 16, 24, 2, base_filters=8, temporal_embeddings=False).cuda().eval()
+    x, ts, md = torch.randn(2, 23, 48, 40).cuda(), torch.randn(2, 12).cuda(), torch.randn(2, 8).cuda()
+    with torch.no_grad():
+        ref = net(x, ts, md)
+        net.freeze_inference()
+        assert torch.equal(net(x, ts, md), ref) and torch.equal(net(x, ts, md), ref)
+        blk = net.model.conv2_0
+        assert blk._frozen is not None and "wf" in blk._frozen[0] and "wf" in blk._frozen[1]
+        # parameters change under a frozen session only through the documented doors
+        sd = {k: (v + 0.05 * torch.randn_like(v) if v.is_floating_point() else v) for k, v in net.state_dict().items()}
+        net.load_state_dict(sd)
+        assert blk._frozen is None
+        new = net(x, ts, md)
+        assert not torch.equal(new, ref)
+        net.freeze_inference()
+        assert torch.equal(net(x, ts, md), new)
+    net.train()
+    assert blk._frozen is None
+    net.eval().freeze_inference().set_precision("fp32")
+    assert blk._frozen is None
