@@ -525,14 +525,15 @@ class BcastCat(torch.autograd.Function):
 # head
 # --------------------------------------------------------------------------- #
 class Head(torch.autograd.Function):
-    """final 1x1 conv + tanh on channel 0 when out_channels == 2 (src/model.py:284-292)."""
+    """final 1x1 conv + tanh on channel 0 when out_channels == 2 (src/model.py:284-292 / :187-193).
+    ``activate=False``: the bare 1x1 conv of the deep-supervision heads (src/model.py:180-185)."""
 
     @staticmethod
-    def forward(ctx, a, C, weight, bias):
+    def forward(ctx, a, C, weight, bias, activate=True):
         a = _as_nhwc(a)
         N, H, W, _ = a.shape
         Co = weight.shape[0]
-        tanh0 = 1 if Co == 2 else 0
+        tanh0 = 1 if (Co == 2 and activate) else 0
         out = torch.empty((N, Co, H, W), dtype=torch.float32, device=a.device)
         w2 = weight.detach().reshape(Co, C).contiguous().float()
         call("mau_head_fwd", a.data_ptr(), _ld(a), w2.data_ptr(), bias.detach().data_ptr(), out.data_ptr(), tanh0,
@@ -559,7 +560,7 @@ class Head(torch.autograd.Function):
         red = red.view(Co, pad8(C) + 8)
         dw = red[:, :C].reshape(wshape).contiguous()
         db = red[:, pad8(C)].contiguous()
-        return da, None, dw, db
+        return da, None, dw, db, None
 
 
 # --------------------------------------------------------------------------- #

@@ -342,7 +342,7 @@ class UrbanPredictor_unetpp(_NetBase):
         x1_3 = self._node(self.conv1_3, [x1_0, x1_1, x1_2], x2_2, emb)
         x0_4 = self._node(self.conv0_4, [x0_0, x0_1, x0_2, x0_3], x1_3, emb)
         if self.deep_supervision:
-            return [F_.Head.apply(a.t, a.C, f.weight, f.bias)
+            return [F_.Head.apply(a.t, a.C, f.weight, f.bias, False)          # bare 1x1 convs, no tanh (src/model.py:180-185)
                     for a, f in ((x0_1, self.final1), (x0_2, self.final2), (x0_3, self.final3), (x0_4, self.final4))]
         return self._head(x0_4)
 

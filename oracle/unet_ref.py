@@ -213,8 +213,9 @@ def unet_forward(sd: State, maps, temp_series, metadata, training: bool,
     return head(x0_1, sd)                                                          # :284-292
 
 
-def unetpp_forward(sd: State, maps, temp_series, metadata, training: bool):
-    """UrbanPredictor_unetpp.forward (deep_supervision=False), src/model.py:123-193.
+def unetpp_forward(sd: State, maps, temp_series, metadata, training: bool, deep_supervision: bool = False):
+    """UrbanPredictor_unetpp.forward, src/model.py:123-193; ``deep_supervision=True`` returns the four bare 1x1
+    convolutions ``final1..final4`` of x0_1..x0_4 (:180-185, no tanh).
 
     Both encoders are always used (:125-126); every decoder node takes
     ``cat([skips..., upsample_to(H,W)(below), emb_map])`` (:136-177) with
@@ -246,6 +247,8 @@ def unetpp_forward(sd: State, maps, temp_series, metadata, training: bool):
     node(2, 2)
     node(1, 3)
     node(0, 4)
+    if deep_supervision:                                                           # :180-185
+        return [F.conv2d(X[(0, j)], sd[f"model.final{j}.weight"], sd[f"model.final{j}.bias"]) for j in (1, 2, 3, 4)]
     return head(X[(0, 4)], sd)                                                     # :187-193
 
 

@@ -9,7 +9,7 @@ Imports ``/root/reference/src/model.py`` (with a no-op ``loguru`` stub: loguru i
 not installed and is used for one log line, src/model.py:202), runs the
 reference modules on seeded inputs on the CPU and writes inputs + expected
 outputs as ``.npz`` (fp32).  No reference source is copied: fixtures are data.
-The fixture ids follow SURVEY.md 8(c): G1..G8.
+The fixture ids follow SURVEY.md 8(c): G1..G8 (+ G9 losses, G10 deep supervision).
 """
 import contextlib
 import io
@@ -272,9 +272,44 @@ def g9_losses():
     npz("g9_losses.npz", **out)
 
 
+def g10_deep_supervision(ref):
+    """U-Net++ with deep_supervision=True: four bare 1x1 heads on x0_1..x0_4 (src/model.py:180-185), train-mode
+    forward/backward of the summed MSE of the four outputs, and the eval-mode outputs."""
+    torch.manual_seed(70)
+    kw = dict(model_type="unet++", spatial_channels=6, seq_len=8, temporal_dim=8, meta_features=4, meta_dim=8, lstm_dim=12,
+              out_channels=2, base_filters=4, deep_supervision=True)
+    net = quiet(ref.UrbanPredictor, **kw)
+    g = torch.Generator().manual_seed(1070)
+    randomize_bn(net, g)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    B, H, W = 2, 32, 40
+    x, ts, md = torch.randn(B, 6, H, W, generator=g), torch.randn(B, 8, generator=g), torch.randn(B, 4, generator=g)
+    tgt = torch.randn(B, 2, H, W, generator=g)
+    net.eval()
+    with torch.no_grad():
+        outs_eval = net(x, ts, md)
+    net.train()
+    outs = net(x, ts, md)
+    assert isinstance(outs, list) and len(outs) == 4
+    loss = sum(F.mse_loss(o, tgt) for o in outs)
+    loss.backward()
+    grads = {f"grad/{k}": p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    nograd = [k for k, p in net.named_parameters() if p.grad is None]
+    meta = dict(kw=kw, B=B, H=H, W=W, nograd=nograd)
+    npz("g10_unetpp_deepsup.npz", x=x, ts=ts, md=md, tgt=tgt, loss=loss.detach().reshape(1),
+        meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8),
+        **{f"out_train{j}": o for j, o in enumerate(outs)}, **{f"out_eval{j}": o for j, o in enumerate(outs_eval)},
+        **sd_arrays("sd0", sd0), **grads)
+
+
 def main():
     ref = import_reference()
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                      # regenerate selected fixtures only: make_golden.py g10 ...
+        for name in sys.argv[1:]:
+            fn = {"g10": lambda: g10_deep_supervision(ref)}[name]
+            fn()
+        return
     g1_vgg(ref)
     g2_spatial(ref)
     g3_bottleneck(ref)
@@ -290,6 +325,7 @@ def main():
     g7_full_summary(ref)
     g8_syncbn(ref)
     g9_losses()
+    g10_deep_supervision(ref)
 
 
 if __name__ == "__main__":

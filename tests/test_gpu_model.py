@@ -285,3 +285,38 @@ def test_frozen_inference_matches_and_unfreezes(mau):
     assert blk._frozen is None
     net.eval().freeze_inference().set_precision("fp32")
     assert blk._frozen is None
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_g10_unetpp_deep_supervision(mau, prec):
+    """deep_supervision=True: list of four bare 1x1-conv outputs (no tanh, src/model.py:180-185), gradients of their
+    summed MSE; fp32 <= 1e-3 against the reference fixture, bf16 by relative L2."""
+    d = load_npz("g10_unetpp_deepsup.npz")
+    net, m = build(mau, d, prec)
+    x, ts, md, tgt = (t(d[k]).cuda() for k in ("x", "ts", "md", "tgt"))
+    tol_out, tol_l2 = (1e-3, None) if prec == "fp32" else (None, 6e-2)
+    net.eval()
+    with torch.no_grad():
+        outs = net(x, ts, md)
+    assert isinstance(outs, list) and len(outs) == 4
+    for j, o in enumerate(outs):
+        ref = t(d[f"out_eval{j}"])
+        assert o.shape == ref.shape
+        assert (rel_err(o.cpu(), ref) < tol_out) if tol_out else (rel_l2(o.cpu(), ref) < tol_l2)
+    net.train()
+    outs = net(x, ts, md)
+    for j, o in enumerate(outs):
+        ref = t(d[f"out_train{j}"])
+        assert (rel_err(o.cpu(), ref) < tol_out) if tol_out else (rel_l2(o.cpu(), ref) < tol_l2)
+    loss = sum(mau.compute_loss_mse(o, tgt)["total"] for o in outs)
+    assert abs(float(loss) - float(d["loss"][0])) < (1e-4 if prec == "fp32" else 5e-2) * abs(float(d["loss"][0]))
+    loss.backward()
+    params = dict(net.named_parameters())
+    for k in m["nograd"]:
+        assert params[k].grad is None, k
+    if prec == "fp32":
+        for k, gref in sub(d, "grad").items():
+            got = params[k].grad.cpu()
+            if k.endswith(".conv1.bias") or k.endswith(".conv2.bias"):
+                continue                                         # identically zero here, rounding noise in the reference
+            assert rel_err(got, gref) < 1e-3 or float((got - gref).abs().max()) < 1e-7, k

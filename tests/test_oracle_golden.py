@@ -200,3 +200,29 @@ def test_g9_losses_oracle():
         r2["l1_gradient"].backward()
         assert torch.equal(r2["pixel"].detach().reshape(1), t(d[f"{tag}/l1"]))
         assert torch.equal(o.grad, t(d[f"{tag}/d_l1_gradient"]))
+
+
+def test_g10_unetpp_deep_supervision():
+    """deep_supervision=True (src/model.py:180-185): four bare 1x1 heads, no tanh; forward (eval + train) and the
+    gradients of the summed MSE against the fixture generated from the reference."""
+    import torch.nn.functional as F
+    d = load_npz("g10_unetpp_deepsup.npz")
+    m = meta_of(d)
+    x, ts, md, tgt = (t(d[k]) for k in ("x", "ts", "md", "tgt"))
+    sd = R.clone_state(sub(d, "sd0"))
+    with torch.no_grad():
+        outs = R.unetpp_forward(sd, x, ts, md, False, deep_supervision=True)
+    assert len(outs) == 4
+    for j, o in enumerate(outs):
+        assert rel_err(o, t(d[f"out_eval{j}"])) <= 2e-6
+    sd = R.clone_state(sub(d, "sd0"), requires_grad=True)
+    outs = R.unetpp_forward(sd, x, ts, md, True, deep_supervision=True)
+    for j, o in enumerate(outs):
+        assert rel_err(o, t(d[f"out_train{j}"])) <= 2e-6
+    loss = sum(F.mse_loss(o, tgt) for o in outs)
+    assert abs(float(loss) - float(d["loss"][0])) <= 1e-6 * abs(float(d["loss"][0]))
+    loss.backward()
+    for k, g in sub(d, "grad").items():
+        assert rel_err(sd[k].grad, g) <= 5e-5 or float((sd[k].grad - g).abs().max()) < 1e-7, k
+    for k in m["nograd"]:
+        assert sd[k].grad is None, k                       # model.final.* is unused under deep supervision
