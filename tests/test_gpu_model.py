@@ -329,10 +329,13 @@ MATRIX = [
     ("unet", 9, 5, 2, 3, 8, dict(temporal_embeddings=False, metadata_embeddings=True), (1, 48, 32)),   # three output channels, batch of one
     ("unet++", 4, 6, 5, 1, 6, {}, (2, 35, 33)),
     ("unet++", 6, 4, 4, 2, 8, {}, (3, 32, 48)),
+    ("unet", 6, 4, 4, 2, 8, dict(temporal_embeddings=False, metadata_embeddings=True), (2, 16, 16)),    # bottleneck of 1x1 pixels
+    ("unet", 6, 4, 4, 2, 8, dict(temporal_embeddings=True, metadata_embeddings=True), (3, 17, 19)),     # 17 -> 8 -> 4 -> 2 -> 1, every up-step re-sized
+    ("unet++", 6, 4, 4, 2, 8, {}, (2, 18, 17)),
 ]
 
 
-@pytest.mark.parametrize("cfg", MATRIX, ids=[f"{c[0]}-C{c[1]}-o{c[4]}-b{c[5]}" for c in MATRIX])
+@pytest.mark.parametrize("cfg", MATRIX, ids=[f"{c[0]}-C{c[1]}-o{c[4]}-b{c[5]}-{c[7][1]}x{c[7][2]}" for c in MATRIX])
 def test_fp32_matches_oracle_on_constructor_matrix(mau, cfg):
     """Corners of the constructor surface the reference fixtures do not visit (temporal-only embeddings, out_channels
     1 and 3, channel counts that are not multiples of 8, batch of one): the module in fp32 mode against the pinned
