@@ -16,8 +16,9 @@
 //               src/model.py:248-259) -- the tiled map never exists in HBM
 //   epilogue  : bias, BatchNorm partial statistics from the fp32 accumulators (wave shuffles + LDS),
 //               output tile staged through LDS and stored as whole 128-byte pixel rows
-//   grid      : 1-D, remapped so that the cout tiles of one pixel tile run back to back on ONE XCD
-//               (its L2 serves the re-read of the halo tile); pure speed, no correctness dependence.
+//   grid      : 1-D persistent; every XCD owns a contiguous range of pixel tiles (image order) and runs the cout
+//               tiles of one pixel tile back to back: its L2 serves halo overlap and input re-reads; pure speed,
+//               no correctness dependence.
 //
 // Replaces nn.Conv2d(.,.,3,padding=1) + the statistics half of nn.BatchNorm2d of VGGBlock
 // (reference src/model.py:12-15).
