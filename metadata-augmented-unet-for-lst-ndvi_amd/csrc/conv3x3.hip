@@ -500,7 +500,7 @@ int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_
       MAU_LAUNCH(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
       p.emb_lp = emb_ws;
     }
-    return launch_conv_bf16_v2(p, st);
+    return launch_conv_bf16_v2(p, false, st);
   }
   set_error("bad dtype %d", dtype);
   return MAU_ERR_ARG;
@@ -532,7 +532,7 @@ int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* em
       MAU_LAUNCH(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
       p.emb_lp = emb_ws;
     }
-    return launch_wgrad_bf16_v2(p, st);        // split-K partial slabs, plain stores (no memset needed)
+    return launch_wgrad_bf16_v2(p, false, st);        // split-K partial slabs, plain stores (no memset needed)
   }
   MAU_REQUIRE(dtype == MAU_F32, "bad dtype %d", dtype);
   if (hipMemsetAsync(acc, 0, mau_conv3x3_wgrad_acc_elems(dtype, N, H, W, Cout, C0 + E) * sizeof(float), st) != hipSuccess) {

@@ -461,7 +461,7 @@ static int launch_epi(const ConvP& p, hipStream_t st) {
   return v2::launch<BN, MT, NW, v2::EPI_PLAIN>(p, st);
 }
 
-int launch_conv_bf16_v2(const ConvP& p, hipStream_t st) {
+int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
   if (p.post_scale != nullptr && p.slab != nullptr) {
     set_error("conv3x3_fwd: post_scale/post_shift and the statistics slab are mutually exclusive");
     return MAU_ERR_ARG;

@@ -1,24 +1,36 @@
-// conv3x3_wgrad_bf16.hip -- bf16 weight gradient of the 3x3 convolution on gfx950:
+// conv3x3_wgrad_bf16.hip -- 16-bit (bf16 / fp16) weight gradient of the 3x3 convolution on gfx950:
 //     dW[tap][co][ci] = sum over pixels  dY[pix][co] * X[pix + tap][ci]
 // as 9 GEMMs that share their operands:  M = co, N = ci, K = pixels.
 //
 //   workgroup : BCO (64 | 128) output channels x 64 input channels x all 9 taps
-//   wave      : 32 co x 32 ci x 9 taps = 9 accumulator tiles (144 accumulator registers);
-//               the dY fragment of a k16 step is read once and used for the 9 taps
+//   wave      : 32 co x 32 ci x 9 taps = 9 accumulator tiles (144 accumulator registers)
 //   K loop    : stages of one 8x16 pixel tile: dY tile [128 pix][BCO] + X halo tile [180 pix][64]
-//   staging   : LDS-DMA (global_load_lds_dwordx4), two stages in flight, one barrier per stage
 //   operands  : both GEMM operands are K(pixel)-major in memory (NHWC) but the MFMA wants 8
 //               consecutive k per lane -> ds_read_b64_tr_b16 (hardware transpose) straight from the
 //               [pixel][channel] image; rows are XOR-swizzled in 16-byte chunks through the DMA
-//               SOURCE address so that the 4 rows x 64 bytes a half-wave reads hit distinct banks
+//               SOURCE address so that the 4 rows x 64 bytes a half-wave reads hit distinct banks.
+//               The loop walks HALO rows: the X fragment of (halo row R, column shift dx) is read ONCE and
+//               multiplied with the dY fragments of the (up to) three tile rows R, R-1, R-2 it is a tap of
+//               (dy = 0, 1, 2): 38 fragment reads per 72 MFMAs instead of 80.
+//   pipeline  : the fragment reads are inline-asm ds_read_b64_tr_b16 into a register ring, DEPTH steps
+//               ahead of the MFMAs that consume them, retired by hand-counted s_waitcnt lgkmcnt(N) (hipcc
+//               models an LDS-DMA as touching LDS and turns every compiler-visible LDS dependency into a
+//               full drain while one is pending).  Staging: LDS-DMA (global_load_lds_dwordx4), two stages;
+//               a stage = s_waitcnt vmcnt(0) + raw s_barrier at its TOP (the stage's own DMAs were issued a
+//               whole stage earlier), then the next stage's wave-DMAs are issued one at a time between the
+//               MFMA groups with select-only (branch-free) source addressing: they stay in flight while the
+//               current stage multiplies, and no wait on the vector-memory counter sits between their issue
+//               and the MFMAs.
 //   reduction : every workgroup owns a pixel range (split-K) and writes its partial with plain
 //               coalesced stores into slab [split][9][Cout64][Cin64]; the splits are summed in
 //               fixed order by the unpack kernel -> bitwise reproducible, no float atomics
 //               (the guide prices float atomics at ~1.3 TB/s chip-wide vs ~6 TB/s plain stores).
+//               The 64-channel variant runs two wave groups that split each tile's rows; their
+//               accumulators are added through LDS in a fixed order before the store (one slab per workgroup).
 //
 // Replaces autograd's weight gradient of nn.Conv2d(.,.,3,padding=1) (reference src/model.py:12,14
 // under loss.backward(), src/train.py:252).
-#include "conv_common.h"
+#include "igemm_bf16_util.h"
 
 namespace mau {
 
@@ -26,25 +38,65 @@ namespace wg2 {
 constexpr int TH = 8, TW = 16, HW_ = TW + 2, HALO = (TH + 2) * (TW + 2);   // 180
 constexpr int BCI = 64;
 constexpr int XROW = BCI * 2;                       // 128-byte rows of the X halo image
+constexpr int DEPTH = 2;                            // fragment reads run this many steps ahead of their MFMAs
 
-typedef __attribute__((address_space(3))) void* lds_ptr;
-typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
-typedef __attribute__((address_space(1))) const void* glb_ptr;
+using igemm::glb_ptr;
+using igemm::lds_ptr;
+using igemm::static_for;
+using igemm::wait_vmcnt;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // chunk swizzles (16-byte chunks): 4 consecutive rows x 64 bytes must cover all 64 banks
 __device__ __forceinline__ int swz128(int row) { return ((row >> 1) & 1) << 2; }   // 128-byte rows
 __device__ __forceinline__ int swz256(int row) { return (row & 3) << 2; }          // 256-byte rows
 
-__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lo, int hi_delta) {
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(lo));
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(lo + hi_delta));
-  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+// one k16 operand fragment = two transposed 8-byte reads (k 0..3 | 4..7 of the lane half's 8 pixels)
+struct Frag {
+  u32x2 lo, hi;
+};
+template <int OFF, int HI>
+__device__ __forceinline__ void tr_read(Frag& f, unsigned addr) {
+  static_assert(OFF >= 0 && OFF + HI < 65536, "ds offset field");
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=v"(f.lo), "=v"(f.hi)
+               : "v"(addr), "n"(OFF), "n"(OFF + HI));
+}
+// wait until at most N of this wave's LDS operations are outstanding; re-defines the fragments about to be
+// consumed so that their MFMAs cannot be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void land(Frag& a, Frag& b) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : "n"(N));
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_frag(const Frag& a, const Frag& b, f32x16 c) {
+  const u32x4 av = __builtin_shufflevector(a.lo, a.hi, 0, 1, 2, 3), bv = __builtin_shufflevector(b.lo, b.hi, 0, 1, 2, 3);
+  if constexpr (F16) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+  }
 }
 
-// KG = number of wave groups that split the K (pixel) range of every stage between them: KG = 2 gives the
-// 64-channel variant 8 waves (two per SIMD) instead of 4; each group keeps its own accumulators and writes
-// its own partial slab (the split-sum downstream adds them like any other split).
-template <int BCO, int KG>
+// Step schedule of one stage for a wave group that owns ROWS tile rows: step s = (halo row R = s / 3, dx = s % 3);
+// the step with dx == 0 of a halo row R < ROWS also carries the dY fragment of tile row R.
+template <int ROWS>
+struct Sched {
+  static constexpr int NSTEP = (ROWS + 2) * 3;
+  static constexpr bool carries_a(int s) { return s % 3 == 0 && s / 3 < ROWS; }
+  static constexpr int reads(int s) { return s < NSTEP ? (carries_a(s) ? 4 : 2) : 0; }
+  // LDS operations issued after those of step s when step s is consumed
+  static constexpr int behind(int s) {
+    int n = 0;
+    for (int j = s + 1; j <= s + DEPTH; ++j) n += reads(j);
+    return n;
+  }
+};
+
+// KG = number of wave groups that split the tile rows of every stage between them: KG = 2 gives the
+// 64-channel variant 8 waves (two per SIMD) instead of 4.
+template <int BCO, int KG, bool F16>
 __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int nsplit) {
   constexpr int NW = BCO / 16 * KG;                  // waves: (BCO/32) x 2 x KG
   constexpr int WCO = BCO / 32;
@@ -55,67 +107,75 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
   constexpr int DY_BYTES = DY_Q * 1024;
   constexpr int STAGE = DY_BYTES + X_Q * 1024;
   constexpr int TOT_Q = DY_Q + X_Q;
-  constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;
+  constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;    // every wave issues exactly PER_WAVE DMAs per stage (pad slots: zero page)
+  constexpr int ROWS = TH / KG;                      // tile rows of a wave group
+  using S = Sched<ROWS>;
+  constexpr int NSTEP = S::NSTEP;
+  static_assert(PER_WAVE <= NSTEP, "one DMA per step at most");
+  static_assert(ROWS % 2 == 0, "row parity of the halo swizzle");
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * max(STAGE, PER_WAVE * NW KiB)
+  constexpr int STRIDE = PER_WAVE * NW * 1024 > STAGE ? PER_WAVE * NW * 1024 : STAGE;   // stage pitch incl. pad slots
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = wave % WCO, wci = (wave / WCO) & 1, kg = wave / (2 * WCO);
   const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
-  const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(p.x);
-  const bf16* __restrict__ dyg = reinterpret_cast<const bf16*>(p.dy);
-  const bf16* __restrict__ emb = reinterpret_cast<const bf16*>(p.emb_lp);
-  const bf16* zero = reinterpret_cast<const bf16*>(g_zero_page);
+  const unsigned short* __restrict__ xg = reinterpret_cast<const unsigned short*>(p.x);
+  const unsigned short* __restrict__ dyg = reinterpret_cast<const unsigned short*>(p.dy);
+  const unsigned short* __restrict__ emb = reinterpret_cast<const unsigned short*>(p.emb_lp);
+  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page);
 
-  // ---- per-lane DMA slots (tile independent part) ----
-  int s_row[PER_WAVE], s_c[PER_WAVE];               // row inside the tile image, first channel of the 16-byte chunk
+  // ---- per-lane DMA slots (tile independent part).  Slot q = wave + j * NW of a stage: q < DY_Q is a dY slot, which
+  // for every wave means j < DY_Q / NW (compile time); source selection is selects only, no control flow at issue time ----
+  static_assert(DY_Q % NW == 0, "dY / halo slots must split at a compile-time j");
+  constexpr int DY_J = DY_Q / NW;
+  int s_ry[PER_WAVE], s_rx[PER_WAVE], s_c[PER_WAVE];   // pixel offset inside the tile (halo: -1..), first channel of the 16-byte chunk
+  bool s_t[PER_WAVE], s_e[PER_WAVE];                   // source class: tensor (dY or X) / X broadcast embedding / neither = zero page
 #pragma unroll
   for (int j = 0; j < PER_WAVE; ++j) {
     const int q = wave + j * NW;
-    s_row[j] = -1;
-    s_c[j] = 0;
-    if (q < DY_Q) {
+    s_ry[j] = s_rx[j] = s_c[j] = 0;
+    s_t[j] = s_e[j] = false;
+    if (j < DY_J) {
       const int slot = q * 64 + lane;
       const int row = slot / DY_CPR, pc = slot % DY_CPR;
       const int lc = pc ^ (BCO == 64 ? swz128(row) : swz256(row));
-      s_row[j] = row;
+      s_ry[j] = row >> 4;
+      s_rx[j] = row & 15;
       s_c[j] = co0 + 8 * lc;
+      s_t[j] = s_c[j] < p.lddy;
     } else if (q < TOT_Q) {
       const int slot = (q - DY_Q) * 64 + lane;
       const int row = slot >> 3, pc = slot & 7;
       const int lc = pc ^ swz128(row);
-      s_row[j] = row < HALO ? row : -1;
-      s_c[j] = ci0 + 8 * lc;
+      const int c = ci0 + 8 * lc;
+      s_ry[j] = row / HW_ - 1;
+      s_rx[j] = row % HW_ - 1;
+      s_c[j] = c;
+      s_t[j] = row < HALO && (c < p.C0 || (p.E == 0 && c < p.ldx));
+      s_e[j] = row < HALO && !s_t[j] && c < p.C0 + p.E;
     }
   }
-
-  auto issue = [&](int stage, int tile) {
-    int tt = tile;
-    const int txi = tt % p.tilesX;
-    tt /= p.tilesX;
-    const int tyi = tt % p.tilesY;
-    const int n = tt / p.tilesY;
-    const int ty0 = tyi * TH, tx0 = txi * TW;
-#pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
-      const int q = wave + j * NW;                   // wave-uniform
-      if (q < TOT_Q) {
-        const bf16* src = zero;
-        const int row = s_row[j], c = s_c[j];
-        if (q < DY_Q) {
-          const int gy = ty0 + (row >> 4), gx = tx0 + (row & 15);
-          if (gy < p.H && gx < p.W && c < p.lddy) src = dyg + ((size_t)(n * p.H + gy) * p.W + gx) * (size_t)p.lddy + c;
-        } else if (row >= 0) {
-          const int gy = ty0 + row / HW_ - 1, gx = tx0 + row % HW_ - 1;
-          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-            if (c < p.C0 || (p.E == 0 && c < p.ldx)) src = xg + ((size_t)(n * p.H + gy) * p.W + gx) * (size_t)p.ldx + c;
-            else if (c < p.C0 + p.E) src = emb + (size_t)n * p.E + (c - p.C0);
-          }
-        }
-        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + stage * STAGE + q * 1024), 16, 0, 0);
-      }
+  // one wave-DMA (1 KiB); (n, ty0, tx0) wave-uniform; predicates and selects only (as conv3x3_bf16.hip's issue_slot)
+  auto issue_slot = [&](auto jc, int stage, int n, int ty0, int tx0) {
+    constexpr int j = decltype(jc)::value;
+    const int q = wave + j * NW;
+    const int gy = ty0 + s_ry[j], gx = tx0 + s_rx[j];
+    const bool inb = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+    const size_t pix = (size_t)((n * p.H + gy) * p.W + gx);
+    const bool is_t = inb & s_t[j];
+    const unsigned short* src;
+    if constexpr (j < DY_J) {
+      const unsigned short* pt = dyg + pix * (size_t)p.lddy + s_c[j];
+      src = is_t ? pt : zero;
+    } else {
+      const unsigned short* pt = xg + pix * (size_t)p.ldx + s_c[j];
+      const unsigned short* pe = emb + (n * p.E + (s_c[j] - p.C0));
+      const bool is_e = inb & s_e[j];
+      src = is_t ? pt : (is_e ? pe : zero);
     }
+    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + stage * STRIDE + q * 1024), 16, 0, 0);
   };
 
   // ---- per-lane transposed-read offsets ----
@@ -125,13 +185,11 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
   // A (dY): row = trow*16 + 8h + 4s + q  -> swizzle term depends on q only
   const int a_chunk = wco * 4 + 2 * tg + (tp >> 1);
   const int a_row0 = 8 * th + tq;
-  const int a_off = a_row0 * DYROW + 16 * (a_chunk ^ (BCO == 64 ? swz128(a_row0) : swz256(a_row0))) + 8 * (tp & 1);
-  // B (X halo): row = (trow+dy)*18 + dx + 8h + 4s + q; (row>>1)&1 depends on ((trow+dy)&1, dx, q)
+  const int a_off = a_row0 * DYROW + 16 * (a_chunk ^ (BCO == 64 ? swz128(a_row0) : swz256(a_row0))) + 8 * (tp & 1) + kg * ROWS * 16 * DYROW;
+  // B (X halo): row = R*18 + dx + 8h + 4s + q; the swizzle only toggles byte-offset bit 6 and depends on
+  // (R & 1, dx, q) -> 6 per-lane bases (dx = 0..2, parity c = 0..1); everything else is an immediate.
   const int b_chunk = wci * 4 + 2 * tg + (tp >> 1);
-  // address = (lane_base ^ swizzle_bit6) + row constants: the swizzle only toggles byte-offset bit 6 and
-  // depends on ((trow+dy)&1, dx, q) -> 6 per-lane bases (dx = 0..2, parity c = 0..1); everything else is an
-  // immediate (multiples of the 128-byte row).
-  const int b_lane = DY_BYTES + (8 * th + tq) * XROW + 16 * b_chunk + 8 * (tp & 1);
+  const int b_lane = DY_BYTES + (8 * th + tq) * XROW + 16 * b_chunk + 8 * (tp & 1) + kg * ROWS * HW_ * XROW;
   int b_base[3][2];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
@@ -144,37 +202,94 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
   // ---- split-K: this workgroup's pixel tiles ----
   const int split = blockIdx.x;
   const int per = (p.nTiles + nsplit - 1) / nsplit;
   const int t0 = split * per, t1 = min(p.nTiles, t0 + per);
   if (t0 < t1) {
-    issue(0, t0);
-    __syncthreads();
+    // (n, ty0, tx0) of the tile being LOADED, advanced incrementally (wave-uniform scalars)
+    int ltx = t0 % p.tilesX, lty = (t0 / p.tilesX) % p.tilesY, ln = t0 / (p.tilesX * p.tilesY);
+    static_for<0, PER_WAVE>([&](auto jc) { issue_slot(jc, 0, ln, lty * TH, ltx * TW); });
     int stage = 0;
     for (int tile = t0; tile < t1; ++tile) {
-      if (tile + 1 < t1) issue(stage ^ 1, tile + 1);
-      const unsigned char* sb = smem + stage * STAGE;
-      constexpr int ROWS = TH / KG;                    // tile rows of this wave group
-      const unsigned char* sbk = sb + kg * ROWS * HW_ * XROW;
-      const unsigned char* sak = sb + a_off + kg * ROWS * 16 * DYROW;
-#pragma unroll
-      for (int tr = 0; tr < ROWS; ++tr) {              // (trow = kg*ROWS + tr; ROWS is even, so parity(trow) = parity(tr))
-        const bf16x8 a = tr_pair(sak + tr * 16 * DYROW, 4 * DYROW);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int dy = tap / 3, dx = tap % 3;
-          const bf16x8 b = tr_pair(sbk + b_base[dx][(tr + dy) & 1] + ((tr + dy) * HW_ + dx) * XROW, 4 * XROW);
-          acc[tap] = mfma32(a, b, acc[tap]);
+      wait_vmcnt<0>();                                 // this wave's DMAs of the stage about to be multiplied (issued a stage ago)
+      __builtin_amdgcn_s_barrier();                    // ... everyone's have landed, and everyone is done reading the other buffer
+      // the tile to load next; after the last one the current tile is re-fetched into the idle buffer (nobody reads it)
+      if (tile + 1 < t1) {
+        if (++ltx == p.tilesX) {
+          ltx = 0;
+          if (++lty == p.tilesY) {
+            lty = 0;
+            ++ln;
+          }
         }
       }
-      __syncthreads();
+      const int nty0 = lty * TH, ntx0 = ltx * TW, nn = ln;
+      const unsigned sb = lds0 + stage * STRIDE;
+      const unsigned aa = sb + a_off;
+      const unsigned bb[3][2] = {{sb + b_base[0][0], sb + b_base[0][1]}, {sb + b_base[1][0], sb + b_base[1][1]}, {sb + b_base[2][0], sb + b_base[2][1]}};
+      Frag fa[4], fb[DEPTH + 1];
+      auto fetch = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s < NSTEP) {
+          constexpr int R = s / 3, dx = s % 3;
+          if constexpr (S::carries_a(s)) tr_read<R * 16 * DYROW, 4 * DYROW>(fa[R & 3], aa);
+          tr_read<(R * HW_ + dx) * XROW, 4 * XROW>(fb[s % (DEPTH + 1)], bb[dx][R & 1]);
+        }
+      };
+      static_for<0, DEPTH>([&](auto sc) { fetch(sc); });
+      static_for<0, NSTEP>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int R = s / 3, dx = s % 3;
+        fetch(std::integral_constant<int, s + DEPTH>{});
+        land<S::behind(s)>(fa[(R < ROWS ? R : ROWS - 1) & 3], fb[s % (DEPTH + 1)]);
+        static_for<0, 3>([&](auto dc) {
+          constexpr int dy = decltype(dc)::value, tr = R - dy;
+          if constexpr (tr >= 0 && tr < ROWS) acc[dy * 3 + dx] = mfma_frag<F16>(fa[tr & 3], fb[s % (DEPTH + 1)], acc[dy * 3 + dx]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        // the next stage's DMAs, spread over the steps
+        static_for<0, PER_WAVE>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if constexpr (s == (j * NSTEP) / PER_WAVE) {
+            issue_slot(jc, stage ^ 1, nn, nty0, ntx0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+      });
       stage ^= 1;
     }
+    wait_vmcnt<0>();                                   // the idle re-fetch must land before the LDS is reused / released
   }
 
+  const int slab = blockIdx.x;
+  float* out = p.acc + (size_t)slab * 9 * p.CoutPad * p.CinPad;
+  if constexpr (KG == 2) {
+    // ---- the two wave groups add their accumulators through LDS (fixed order: group 0 + group 1), 3 taps per round ----
+    __builtin_amdgcn_s_barrier();
+    float* red = reinterpret_cast<float*>(smem) + (size_t)(wave % (NW / 2)) * (3 * 16 * 64);
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+      if (kg == 1) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[round * 3 + t][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[round * 3 + t][r] += red[(t * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (kg != 0) return;
+  }
   // ---- partial slab: [split][tap][CoutPad][CinPad], 128 contiguous bytes per half-wave ----
-  float* out = p.acc + (size_t)(split * KG + kg) * 9 * p.CoutPad * p.CinPad;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -185,18 +300,23 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
     }
 }
 
-template <int BCO, int KG>
+template <int BCO, int KG, bool F16>
 static int launch(const WgradP& p, int nsplit, hipStream_t st) {
+  constexpr int NW = BCO / 16 * KG;
   constexpr int DY_Q = TH * TW * (BCO / 8) / 64;
   constexpr int X_Q = (HALO * 8 + 63) / 64;
-  constexpr size_t lds = 2 * (size_t)(DY_Q + X_Q) * 1024;
+  constexpr int PER_WAVE = (DY_Q + X_Q + NW - 1) / NW;
+  constexpr size_t stage = (size_t)(PER_WAVE * NW > DY_Q + X_Q ? PER_WAVE * NW : DY_Q + X_Q) * 1024;
+  constexpr size_t red = KG == 2 ? (size_t)(NW / 2) * 3 * 16 * 64 * sizeof(float) : 0;
+  constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<BCO, KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<BCO, KG, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(nsplit / KG, p.CoutPad / BCO, p.CinPad / BCI);      // nsplit counts slabs: KG per workgroup
-  MAU_LAUNCH((wgrad_bf16_kernel<BCO, KG>), grid, dim3(BCO * 4 * KG), lds, st, p, nsplit / KG);
+  dim3 grid(nsplit, p.CoutPad / BCO, p.CinPad / BCI);
+  MAU_LAUNCH((wgrad_bf16_kernel<BCO, KG, F16>), grid, dim3(BCO * 4 * KG), lds, st, p, nsplit);
   return check_launch("wgrad_bf16_kernel");
 }
 }  // namespace wg2
@@ -216,31 +336,29 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   if (smax < 1) smax = 1;
   if (smax > 1024) smax = 1024;
   if ((size_t)smax > cap) smax = (int)cap;
-  const int kg = bco == 64 ? 2 : 1;                // slabs written per workgroup (wave groups splitting K)
   int best = 1;
   double best_score = -1.0;
-  for (int s = 1; s <= smax; ++s) {                // s = workgroups along the split axis
-    if ((size_t)s * kg > cap) break;
+  for (int s = 1; s <= smax; ++s) {                // s = workgroups along the split axis = partial slabs
     const long blocks = (long)outTiles * s;
     const long rounds = (blocks + 255) / 256;
     const double eff = (double)blocks / (double)(rounds * 256);
-    const double score = eff - 0.0015 * s * kg;
+    const double score = eff - 0.0015 * s;
     if (score > best_score + 1e-9) {
       best_score = score;
       best = s;
     }
   }
-  return best * kg;
+  return best;
 }
 
-int launch_wgrad_bf16_v2(const WgradP& p, hipStream_t st) {
+int launch_wgrad_bf16_v2(const WgradP& p, bool f16, hipStream_t st) {
   const int nsplit = wgrad_bf16_v2_splits(p.N, p.H, p.W, p.Cout, p.Cin);
   WgradP q = p;
   q.tilesX = ceil_div(p.W, wg2::TW);
   q.tilesY = ceil_div(p.H, wg2::TH);
   q.nTiles = p.N * q.tilesX * q.tilesY;
-  if (p.CoutPad % 128 == 0) return wg2::launch<128, 1>(q, nsplit, st);
-  return wg2::launch<64, 2>(q, nsplit, st);
+  if (p.CoutPad % 128 == 0) return f16 ? wg2::launch<128, 1, true>(q, nsplit, st) : wg2::launch<128, 1, false>(q, nsplit, st);
+  return f16 ? wg2::launch<64, 2, true>(q, nsplit, st) : wg2::launch<64, 2, false>(q, nsplit, st);
 }
 
 }  // namespace mau

@@ -55,9 +55,9 @@ struct PackKC {
   static constexpr int value = 16;
 };
 
-int launch_conv_bf16_v2(const ConvP& p, hipStream_t st);
+int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st);   // 16-bit kernels: bf16 or (f16 = true) fp16 operands
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout);
-int launch_wgrad_bf16_v2(const WgradP& p, hipStream_t st);      // writes nsplit partial slabs (plain stores)
+int launch_wgrad_bf16_v2(const WgradP& p, bool f16, hipStream_t st);      // writes nsplit partial slabs (plain stores)
 int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin);
 
 }  // namespace mau
