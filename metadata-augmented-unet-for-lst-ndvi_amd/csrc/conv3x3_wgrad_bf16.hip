@@ -17,10 +17,11 @@
 //               models an LDS-DMA as touching LDS and turns every compiler-visible LDS dependency into a
 //               full drain while one is pending).  Staging: LDS-DMA (global_load_lds_dwordx4), two stages;
 //               a stage = s_waitcnt vmcnt(0) + raw s_barrier at its TOP (the stage's own DMAs were issued a
-//               whole stage earlier), then the next stage's wave-DMAs are issued one at a time between the
-//               MFMA groups with select-only (branch-free) source addressing: they stay in flight while the
-//               current stage multiplies, and no wait on the vector-memory counter sits between their issue
-//               and the MFMAs.
+//               whole stage earlier), then the next stage's wave-DMAs are issued one per step from the head of
+//               the stage, between the MFMA groups, with select-only (branch-free) source addressing: they stay
+//               in flight while the current stage multiplies, and no wait on the vector-memory counter sits
+//               between their issue and the MFMAs.  (A third stage, template NS, bought nothing once the DMAs
+//               were issued at the head.)
 //   reduction : every workgroup owns a pixel range (split-K) and writes its partial with plain
 //               coalesced stores into slab [split][9][Cout64][Cin64]; the splits are summed in
 //               fixed order by the unpack kernel -> bitwise reproducible, no float atomics
@@ -38,7 +39,10 @@ namespace wg2 {
 constexpr int TH = 8, TW = 16, HW_ = TW + 2, HALO = (TH + 2) * (TW + 2);   // 180
 constexpr int BCI = 64;
 constexpr int XROW = BCI * 2;                       // 128-byte rows of the X halo image
-constexpr int DEPTH = 2;                            // fragment reads run this many steps ahead of their MFMAs
+#ifndef WG_DEPTH
+#define WG_DEPTH 2
+#endif
+constexpr int DEPTH = WG_DEPTH;                     // fragment reads run this many steps ahead of their MFMAs
 
 using igemm::glb_ptr;
 using igemm::lds_ptr;
@@ -96,7 +100,7 @@ struct Sched {
 
 // KG = number of wave groups that split the tile rows of every stage between them: KG = 2 gives the
 // 64-channel variant 8 waves (two per SIMD) instead of 4.
-template <int BCO, int KG, bool F16>
+template <int BCO, int KG, bool F16, int NS>
 __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int nsplit) {
   constexpr int NW = BCO / 16 * KG;                  // waves: (BCO/32) x 2 x KG
   constexpr int WCO = BCO / 32;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
   static_assert(PER_WAVE <= NSTEP, "one DMA per step at most");
   static_assert(ROWS % 2 == 0, "row parity of the halo swizzle");
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * max(STAGE, PER_WAVE * NW KiB)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NS * max(STAGE, PER_WAVE * NW KiB)
   constexpr int STRIDE = PER_WAVE * NW * 1024 > STAGE ? PER_WAVE * NW * 1024 : STAGE;   // stage pitch incl. pad slots
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -209,15 +213,12 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
   const int per = (p.nTiles + nsplit - 1) / nsplit;
   const int t0 = split * per, t1 = min(p.nTiles, t0 + per);
   if (t0 < t1) {
-    // (n, ty0, tx0) of the tile being LOADED, advanced incrementally (wave-uniform scalars)
-    int ltx = t0 % p.tilesX, lty = (t0 / p.tilesX) % p.tilesY, ln = t0 / (p.tilesX * p.tilesY);
-    static_for<0, PER_WAVE>([&](auto jc) { issue_slot(jc, 0, ln, lty * TH, ltx * TW); });
-    int stage = 0;
-    for (int tile = t0; tile < t1; ++tile) {
-      wait_vmcnt<0>();                                 // this wave's DMAs of the stage about to be multiplied (issued a stage ago)
-      __builtin_amdgcn_s_barrier();                    // ... everyone's have landed, and everyone is done reading the other buffer
-      // the tile to load next; after the last one the current tile is re-fetched into the idle buffer (nobody reads it)
-      if (tile + 1 < t1) {
+    // (n, ty0, tx0) of the tile being LOADED, advanced incrementally (wave-uniform scalars); past the last tile the cursor
+    // stays there: the tile is re-fetched into an idle buffer (nobody reads it), which keeps the DMA count per stage fixed
+    int lcur = t0, ltx = t0 % p.tilesX, lty = (t0 / p.tilesX) % p.tilesY, ln = t0 / (p.tilesX * p.tilesY);
+    auto advance = [&]() {
+      if (lcur + 1 < t1) {
+        ++lcur;
         if (++ltx == p.tilesX) {
           ltx = 0;
           if (++lty == p.tilesY) {
@@ -226,6 +227,18 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
           }
         }
       }
+    };
+    static_for<0, NS - 1>([&](auto stc) {
+      constexpr int st = decltype(stc)::value;
+      if constexpr (st > 0) advance();
+      static_for<0, PER_WAVE>([&](auto jc) { issue_slot(jc, st, ln, lty * TH, ltx * TW); });
+    });
+    int stage = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+      wait_vmcnt<(NS - 2) * PER_WAVE>();               // this wave's DMAs of the stage about to be multiplied (issued NS - 1 stages ago)
+      __builtin_amdgcn_s_barrier();                    // ... everyone's have landed, and everyone is done reading the buffer refilled next
+      advance();
+      const int lstage = stage == 0 ? NS - 1 : stage - 1;   // buffer multiplied in the previous iteration
       const int nty0 = lty * TH, ntx0 = ltx * TW, nn = ln;
       const unsigned sb = lds0 + stage * STRIDE;
       const unsigned aa = sb + a_off;
@@ -250,16 +263,18 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
           if constexpr (tr >= 0 && tr < ROWS) acc[dy * 3 + dx] = mfma_frag<F16>(fa[tr & 3], fb[s % (DEPTH + 1)], acc[dy * 3 + dx]);
         });
         __builtin_amdgcn_sched_barrier(0);
-        // the next stage's DMAs, spread over the steps
+        // The next stage's DMAs: one per step from the HEAD of the stage.  Measured (scripts/variant_bench.py, same box):
+        // spread evenly over the stage +5 % time (the late ones stall the next stage's head); the two waves of a SIMD
+        // taking turns (one issues while the other multiplies) +4 %: time to land, not issue cost, is what matters.
         static_for<0, PER_WAVE>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
-          if constexpr (s == (j * NSTEP) / PER_WAVE) {
-            issue_slot(jc, stage ^ 1, nn, nty0, ntx0);
+          if constexpr (s == j) {
+            issue_slot(jc, lstage, nn, nty0, ntx0);
             __builtin_amdgcn_sched_barrier(0);
           }
         });
       });
-      stage ^= 1;
+      stage = stage + 1 == NS ? 0 : stage + 1;
     }
     wait_vmcnt<0>();                                   // the idle re-fetch must land before the LDS is reused / released
   }
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
     }
 }
 
-template <int BCO, int KG, bool F16>
+template <int BCO, int KG, bool F16, int NS>
 static int launch(const WgradP& p, int nsplit, hipStream_t st) {
   constexpr int NW = BCO / 16 * KG;
   constexpr int DY_Q = TH * TW * (BCO / 8) / 64;
@@ -308,15 +323,15 @@ static int launch(const WgradP& p, int nsplit, hipStream_t st) {
   constexpr int PER_WAVE = (DY_Q + X_Q + NW - 1) / NW;
   constexpr size_t stage = (size_t)(PER_WAVE * NW > DY_Q + X_Q ? PER_WAVE * NW : DY_Q + X_Q) * 1024;
   constexpr size_t red = KG == 2 ? (size_t)(NW / 2) * 3 * 16 * 64 * sizeof(float) : 0;
-  constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
+  constexpr size_t lds = NS * stage > red ? NS * stage : red;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<BCO, KG, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<BCO, KG, F16, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(nsplit, p.CoutPad / BCO, p.CinPad / BCI);
-  MAU_LAUNCH((wgrad_bf16_kernel<BCO, KG, F16>), grid, dim3(BCO * 4 * KG), lds, st, p, nsplit);
+  MAU_LAUNCH((wgrad_bf16_kernel<BCO, KG, F16, NS>), grid, dim3(BCO * 4 * KG), lds, st, p, nsplit);
   return check_launch("wgrad_bf16_kernel");
 }
 }  // namespace wg2
@@ -357,8 +372,11 @@ int launch_wgrad_bf16_v2(const WgradP& p, bool f16, hipStream_t st) {
   q.tilesX = ceil_div(p.W, wg2::TW);
   q.tilesY = ceil_div(p.H, wg2::TH);
   q.nTiles = p.N * q.tilesX * q.tilesY;
-  if (p.CoutPad % 128 == 0) return f16 ? wg2::launch<128, 1, true>(q, nsplit, st) : wg2::launch<128, 1, false>(q, nsplit, st);
-  return f16 ? wg2::launch<64, 2, true>(q, nsplit, st) : wg2::launch<64, 2, false>(q, nsplit, st);
+#ifndef WG_NS64
+#define WG_NS64 2
+#endif
+  if (p.CoutPad % 128 == 0) return f16 ? wg2::launch<128, 1, true, 2>(q, nsplit, st) : wg2::launch<128, 1, false, 2>(q, nsplit, st);
+  return f16 ? wg2::launch<64, 2, true, WG_NS64>(q, nsplit, st) : wg2::launch<64, 2, false, WG_NS64>(q, nsplit, st);
 }
 
 }  // namespace mau
