@@ -47,9 +47,13 @@ class ConvTimer:
         orig = self._orig
 
         def call(name, *args):
-            if self.enabled and name == "mau_conv3x3_fwd":
-                # args: x, ldx, C0, emb, emb_ws, E, wpk, bias, post_scale, post_shift, y, ldy, Cout, slab, dtype, N, H, W, stream
-                C0, E, Cout, N, H, W = args[2], args[5], args[12], args[15], args[16], args[17]
+            if self.enabled and name in ("mau_conv3x3_fwd", "mau_conv3x3_fwd2"):
+                if name == "mau_conv3x3_fwd":
+                    # args: x, ldx, C0, emb, emb_ws, E, wpk, bias, post_scale, post_shift, y, ldy, Cout, slab, dtype, N, H, W, stream
+                    C0, E, Cout, N, H, W = args[2], args[5], args[12], args[15], args[16], args[17]
+                else:
+                    # args: x, ldx, C0, x1, ldx1, C1, emb, emb_ws, E, wpk, bias, post_scale, post_shift, y, ldy, Cout, slab, dtype, N, H, W, stream
+                    C0, E, Cout, N, H, W = args[2] + args[5], args[8], args[15], args[18], args[19], args[20]
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -69,9 +73,10 @@ class ConvTimer:
         return dict(launches=len(ms), total_ms=sum(ms), total_flop=sum(fl))
 
 
-def cpu_baseline(steps=3):
-    """The oracle's train step (same torch CPU operators as the reference, fp32) on a bounded sample:
-    B = 2 of the same workload (BASELINE config 1)."""
+def cpu_baseline(iters=5, warmup=2):
+    """The oracle (same torch CPU operators as the reference, fp32) on a bounded sample -- B = 2 of the same workload
+    (BASELINE config 1) -- as BASELINE.md section 3 / SURVEY 8(d) ask: 2 warm-ups, median of >= 5 iterations,
+    train step (fwd + MSE + bwd + AdamW), train-mode forward and eval-mode forward timed separately."""
     from oracle import unet_ref as R
     torch.manual_seed(0)
     flags = dict(temporal_embeddings=False, metadata_embeddings=True)
@@ -79,17 +84,57 @@ def cpu_baseline(steps=3):
     params = [sd[k] for k in sd if R.is_param(k)]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-3)
     x, ts, md, tgt = R.synthetic_batch(2)
-    times = []
-    for i in range(steps + 1):
-        t0 = time.perf_counter()
-        R.train_step("unet", sd, opt, x, ts, md, tgt, **flags)
-        dt = time.perf_counter() - t0
-        if i > 0:
-            times.append(dt)
-    med = statistics.median(times)
-    return {"value": 2.0 / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"B=2 of the same workload (U-Net base 64, 6x256x256, fp32, fwd+MSE+bwd+AdamW), "
-                      f"median of {steps} steps after 1 warm-up, {med:.2f} s/step, host has {os.cpu_count()} logical CPUs"}
+
+    def timed(fn):
+        ts_ = []
+        for i in range(warmup + iters):
+            t0 = time.perf_counter()
+            fn()
+            if i >= warmup:
+                ts_.append(time.perf_counter() - t0)
+        return statistics.median(ts_)
+
+    def fwd(training):
+        with torch.no_grad():
+            R.forward("unet", sd, x, ts, md, training, **flags)
+
+    t_step = timed(lambda: R.train_step("unet", sd, opt, x, ts, md, tgt, **flags))
+    t_fwd = timed(lambda: fwd(True))
+    t_eval = timed(lambda: fwd(False))
+    return {"value": round(2.0 / t_step, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "fwd_train_images_s": round(2.0 / t_fwd, 4), "fwd_eval_images_s": round(2.0 / t_eval, 4),
+            "host_logical_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads(),
+            "sample": f"B=2 of the same workload (U-Net base 64, 6x256x256, fp32): median of {iters} iterations after {warmup} warm-ups; "
+                      f"train step (fwd+MSE+bwd+AdamW) {t_step:.2f} s, train-mode forward {t_fwd:.2f} s, eval forward {t_eval:.2f} s"}
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` (N > 1) outside torch.distributed.run: start N ranks as CHILD processes -- this parent has
+    not touched the GPU and never execs -- relay rank 0's JSON line, and fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or not lines:
+        raise SystemExit(proc.returncode or 1)
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
+
+
+def workload_key(args):
+    mode = "infer" if args.infer else "train"
+    extra = "" if args.seq_len == 10 and not args.temporal_embeddings else f"_T{args.seq_len}{'_temb' if args.temporal_embeddings else ''}"
+    return f"{args.model_type}_{args.precision}_b{args.batch}_s{args.size}_c{args.channels}_{mode}{extra}"
 
 
 def main():
@@ -100,16 +145,20 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE: 32)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--model-type", default="unet", choices=["unet", "unet++"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--infer", action="store_true", help="inference-only images/s (eval mode, no_grad): BASELINE configs[4]")
     ap.add_argument("--channels", type=int, default=6, help="input channels (6 = BASELINE configs, 23 = the app's real shape)")
     ap.add_argument("--meta", type=int, default=4)
     ap.add_argument("--no-sync-bn", action="store_true", help="per-GPU BatchNorm statistics (reference semantics per device)")
+    ap.add_argument("--seq-len", type=int, default=10, help="length of the temperature series (reference data: 828, conf/config.yaml:20)")
+    ap.add_argument("--temporal-embeddings", action="store_true", help="U-Net with the LSTM TemporalEncoder on the path (always on for unet++)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; default: the "
-                         "figure committed in profiles/r1/dominant_kernel_summary.json (same workload)")
+                         "figure committed under profiles/ for the same workload (profiles/r2/pmc_summary.json)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])           # before anything touches the GPU
 
     import mau_amd
     from mau_amd import functional as F_
@@ -118,21 +167,21 @@ def main():
 
     rank, local, world = init_process_group_from_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started {world} rank(s)")
+    rccl_ranks = dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     # ---- model / synthetic data --------------------------------------------------
     torch.manual_seed(0)                       # identical replicas on every rank
-    flags = {} if args.model_type == "unet++" else dict(temporal_embeddings=False, metadata_embeddings=True)
-    net = mau_amd.UrbanPredictor(args.model_type, args.channels, 10, 64, args.meta, 64, 96, 2, base_filters=64, **flags)
+    flags = {} if args.model_type == "unet++" else dict(temporal_embeddings=args.temporal_embeddings, metadata_embeddings=True)
+    net = mau_amd.UrbanPredictor(args.model_type, args.channels, args.seq_len, 64, args.meta, 64, 96, 2, base_filters=64, **flags)
     net = net.to(dev).set_precision(args.precision).train()
     g = torch.Generator().manual_seed(1234 + rank)
     B, S = args.batch, args.size
     x = torch.randn(B, args.channels, S, S, generator=g).to(dev)
-    ts = torch.randn(B, 10, generator=g).to(dev)
+    ts = torch.randn(B, args.seq_len, generator=g).to(dev)
     md = torch.randn(B, args.meta, generator=g).to(dev)
     tgt = torch.randn(B, 2, S, S, generator=g).to(dev)
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-3, fused=True)   # conf/config.yaml:41,48,52
@@ -207,22 +256,28 @@ def main():
         return
 
     conv = timer.summary()
-    traffic, traffic_src = args.traffic_bytes, "--traffic-bytes"
-    if traffic is None and args.precision == "bf16" and args.model_type == "unet" and not args.infer and B == 32 and S == 256:
-        try:   # PMC counters cannot be read inside this process: use the committed separate-pass measurement
-            with open(os.path.join(ROOT, "profiles", "r1", "dominant_kernel_summary.json")) as f:
-                traffic = json.load(f)["conv3x3_bf16_kernel (dominant: forward + data gradient)"]["hbm_bytes_per_launch_pmc"]
-            traffic_src = "profiles/r1/dominant_kernel_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"
+    # PMC counters cannot be read inside this process: HBM traffic and the MFMA-busy fraction of the dominant kernel come from the
+    # separate rocprofv3 --pmc passes of THIS workload committed under profiles/ (scripts/profile.sh + scripts/summarize_profile.py)
+    wkey = workload_key(args)
+    traffic, traffic_src, mfma_busy = args.traffic_bytes, "--traffic-bytes", None
+    if traffic is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")) as f:
+                rec = json.load(f)[wkey]
+            traffic, mfma_busy = rec["hbm_bytes_per_launch"], rec.get("mfma_busy")
+            traffic_src = f"profiles/r2/pmc_summary.json[{wkey}]: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"
         except (OSError, KeyError, ValueError):
             traffic = None
-    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same rate
     achieved = conv["total_flop"] / (conv["total_ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
                 "kernel": "conv3x3_igemm_kernel (forward + data-gradient launches)",
                 "launches": conv["launches"], "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
                 "flop_per_launch_avg": conv["total_flop"] / conv["launches"],
-                "share_of_step_time": round(conv["total_ms"] / (elapsed * 1e3), 4)}
+                "share_of_step_time": round(conv["total_ms"] / (elapsed * 1e3), 4),
+                "mfma_busy": mfma_busy,
+                "hbm_gbps": round(traffic / (conv["total_ms"] * 1e-3 / conv["launches"]) / 1e9, 1) if traffic else None}
     result = {
         "metric": ("inference images/sec" if args.infer else "train images/sec") + f" ({S}x{S}x{args.channels}->2 {'U-Net' if args.model_type == 'unet' else 'U-Net++'}, B={B}/GPU)",
         "value": round(B * world * args.steps / elapsed, 2),
@@ -237,9 +292,11 @@ def main():
         "dtype": args.precision,
         "data": "synthetic",
         "config": {"workload": (f"metadata-{args.model_type} base_filters=64, {B}x{args.channels}x{S}x{S} tiles + {args.meta}-dim metadata per GPU, "
+                                + (f"temperature series of {args.seq_len} months, " if (args.seq_len != 10 or args.temporal_embeddings) else "")
                                 + ("eval-mode forward only (inference)" if args.infer else "fwd+MSE+bwd+AdamW (src/train.py:243-256)")),
                    "global_batch": B * world, "parallelism": f"dp{world}",
                    "sync_bn": bool(world > 1 and not args.no_sync_bn)},
+        "rccl_ranks": rccl_ranks,
         "fwd_ms_per_tile": round(fwd_ms_per_tile, 4),
         "final_loss": float(losses[-1]),
         "roofline": roofline,

@@ -14,8 +14,9 @@
  * Internal activation layout ("NHWC-ld"): element (n, y, x, c) of a tensor lives at
  *   base + ((n*H + y)*W + x)*ld + c,   ld % 8 == 0,  ld >= C,
  * and channels [C, roundup(C,8)) are always zero.  `dtype` selects the arithmetic type of
- * activations and packed weights: MAU_F32 (parity mode, exact fp32 MFMA) or
- * MAU_BF16 (throughput mode, bf16 MFMA with fp32 accumulation).  Parameters,
+ * activations and packed weights: MAU_F32 (parity mode, exact fp32 MFMA),
+ * MAU_BF16 (throughput mode, bf16 MFMA with fp32 accumulation) or MAU_F16 (the same kernels on
+ * fp16 operands: 3 more mantissa bits, no loss scaling -- meant for inference).  Parameters,
  * gradients of parameters, BatchNorm statistics and the model's external
  * inputs/outputs are always fp32 in the reference's own layouts (NCHW, OIHW).
  *
@@ -34,6 +35,7 @@ extern "C" {
 
 #define MAU_F32 0
 #define MAU_BF16 1
+#define MAU_F16 2     /* fp16 activations / packed weights, v_mfma_f32_32x32x16_f16, fp32 accumulation (BASELINE configs[4]) */
 
 #define MAU_OK 0
 #define MAU_ERR_ARG 1      /* bad argument (shape, alignment, dtype)      */
@@ -99,6 +101,13 @@ int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout);
 int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* wpk,
                     const float* bias, const float* post_scale, const float* post_shift, void* y, int ldy,
                     int Cout, float* slab, int dtype, int N, int H, int W, mau_stream_t stream);
+/* Same with the input channels taken from TWO tensors and the broadcast vector -- torch.cat([x, x1, broadcast(emb)], 1)
+ * without materialising the concatenation: the decoder's cat([skip, up(low)], 1) (src/model.py:279-282) and U-Net++'s
+ * node inputs (src/model.py:136-177).  x1 (N,H,W) NHWC-ld with C1 channels, ldx1 % 8 == 0; 16-bit dtypes only,
+ * C0 % 16 == 0 (a 16-channel stage reads one tensor); C1 = 0 / x1 = NULL reduces to mau_conv3x3_fwd. */
+int mau_conv3x3_fwd2(const void* x, int ldx, int C0, const void* x1, int ldx1, int C1, const float* emb, void* emb_ws,
+                     int E, const void* wpk, const float* bias, const float* post_scale, const float* post_shift,
+                     void* y, int ldy, int Cout, float* slab, int dtype, int N, int H, int W, mau_stream_t stream);
 /* Weight gradient  dW = x (*) dy  reduced over all pixels, in two steps:
  *   mau_conv3x3_wgrad        -> acc: fp32 split-K partial slabs [nsplit][9][Cout64][Cin64]
  *                               (nsplit = mau_conv3x3_wgrad_splits(...); MAU_F32: one slab, zeroed by the call)
@@ -108,6 +117,10 @@ int mau_conv3x3_wgrad_splits(int dtype, int N, int H, int W, int Cout, int Cin);
 size_t mau_conv3x3_wgrad_acc_elems(int dtype, int N, int H, int W, int Cout, int Cin);
 int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* dy,
                       int lddy, int Cout, float* acc, int dtype, int N, int H, int W, mau_stream_t stream);
+/* weight gradient w.r.t. the two-tensor input of mau_conv3x3_fwd2 (Cin = C0 + C1 + E; C0 % 8 == 0). */
+int mau_conv3x3_wgrad2(const void* x, int ldx, int C0, const void* x1, int ldx1, int C1, const float* emb, void* emb_ws,
+                       int E, const void* dy, int lddy, int Cout, float* acc, int dtype, int N, int H, int W,
+                       mau_stream_t stream);
 int mau_conv3x3_unpack_wgrad(const float* acc, int nsplit, float* dw_oihw, int Cout, int Cin,
                              mau_stream_t stream);
 
@@ -127,7 +140,9 @@ int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* ou
 /* Train mode: sums = [sum(y) | sum(y^2)] (2*C fp64, already all-reduced over ranks when data
  * parallel), count = number of pixels summed.  Writes scale = gamma*invstd, shift = beta - mean*scale,
  * mean, invstd and updates running_mean / running_var (unbiased) / num_batches_tracked exactly as
- * nn.BatchNorm2d(momentum, eps).forward does in training. */
+ * nn.BatchNorm2d(momentum, eps).forward does in training.
+ * count == 0: `sums` has 2*C + 1 elements and sums[2*C] is the pixel count (all-reduced together with the sums, so that
+ * ranks with different local batch sizes still agree on the global statistics). */
 int mau_bn_finalize_train(const double* sums, double count, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked,
                           float momentum, float eps, float* scale, float* shift, float* mean,
@@ -146,12 +161,17 @@ int mau_bn_coeffs_eval(const float* gamma, const float* beta, const float* runni
 /* a = relu(scale*y + shift) on NHWC-ld (pad channels written as 0). */
 int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift, void* a, int lda,
                       int dtype, int64_t npix, int C, mau_stream_t stream);
+/* a = relu(scale*y + shift) AND pooled (N,H/2,W/2) = nn.MaxPool2d(2,2)(a) in ONE pass over y: an encoder block's
+ * output feeds the next level through the pool and the decoder through the skip (src/model.py:268-271). */
+int mau_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const float* shift, void* a, int lda,
+                           void* pooled, int ldp, int dtype, int N, int H, int W, int C, mau_stream_t stream);
 /* Backward, pass 1: dz = da * [scale*y+shift > 0]; per-block partial sums of dz and dz*xhat
  * (xhat = (y-mean)*invstd) into slab [rows][2][ldslab]; returns rows via *rows_out (host). */
 int mau_bn_relu_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale,
                            const float* shift, const float* mean, const float* invstd, float* slab,
                            int ldslab, int dtype, int64_t npix, int C, mau_stream_t stream);
-/* Backward, pass 2: dy = scale*(dz - s1/count - xhat*s2/count); sums = [s1 | s2] fp64 (2*C). */
+/* Backward, pass 2: dy = scale*(dz - s1/count - xhat*s2/count); sums = [s1 | s2] fp64 (2*C);
+ * count == 0: the count is sums[2*C] (see mau_bn_finalize_train). */
 int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale,
                           const float* shift, const float* mean, const float* invstd, const double* sums,
                           double count, void* dy, int lddy, int dtype, int64_t npix, int C,

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("MAU_LIB") or os.path.join(_HERE, "libmau_hip.so")    
 
 MAU_F32 = 0
 MAU_BF16 = 1
+MAU_F16 = 2
 
 _p, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
@@ -36,9 +37,11 @@ PROTOTYPES = {
     "mau_conv3x3_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "mau_conv3x3_num_pixel_tiles": (_i, [_i, _i, _i, _i, _i]),
     "mau_conv3x3_fwd": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "mau_conv3x3_fwd2": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),
     "mau_conv3x3_wgrad_acc_elems": (_sz, [_i, _i, _i, _i, _i, _i]),
     "mau_conv3x3_wgrad": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "mau_conv3x3_wgrad2": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_unpack_wgrad": (_i, [_p, _i, _p, _i, _i, _p]),
     "mau_reduce_rows_ws_elems": (_sz, [_i, _i]),
     "mau_reduce_rows_f64": (_i, [_p, _i, _i, _i, _p, _p, _p]),
@@ -49,6 +52,7 @@ PROTOTYPES = {
     "mau_bn_stats_finalize_train": (_i, [_p, _i, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i, _p]),
     "mau_bn_coeffs_eval": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p]),
     "mau_bn_relu_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _i64, _i, _p]),
+    "mau_bn_relu_apply_pool": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_bn_relu_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
     "mau_bn_relu_bwd_apply": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _d, _p, _i, _i, _i64, _i, _p]),
     "mau_bn_bwd_rows": (_i, [_i64]),

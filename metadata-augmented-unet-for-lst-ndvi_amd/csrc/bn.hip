@@ -69,6 +69,7 @@ __global__ void bn_finalize_train_kernel(const double* __restrict__ sums, double
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
+  if (count <= 0.0) count = sums[2 * C];              // data parallel: the all-reduced pixel count travels with the sums
   const double mean = sums[c] / count;
   double var = sums[C + c] / count - mean * mean;     // biased variance (normalisation)
   if (var < 0.0) var = 0.0;
@@ -211,6 +212,52 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
   }
 }
 
+// a = relu(scale*y + shift) AND p = maxpool2x2(a) in one pass over y (an encoder block's output feeds the next level
+// through nn.MaxPool2d(2,2) and the decoder through the skip connection: reference src/model.py:268-271).
+// One thread = one 2x2 window x 8 channels; grid = (x-chunks of the window row, window rows incl. a last odd row, images).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, T* __restrict__ a, int lda,
+                                                                 T* __restrict__ pl, int ldp, int H, int W, int C, int C8) {
+  const int nv = C8 >> 3, Wc = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Wc * nv) return;
+  const int xo = idx / nv, c = (idx - xo * nv) * 8;
+  const int yo = blockIdx.y, n = blockIdx.z;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool ok = c + j < C;
+    sc[j] = ok ? scale[c + j] : 0.f;
+    sh[j] = ok ? shift[c + j] : 0.f;
+  }
+  const int y0 = 2 * yo, x0 = 2 * xo;
+  const bool hasx = x0 + 1 < W, hasy = y0 + 1 < H;
+  const size_t row0 = ((size_t)n * H + y0) * W, row1 = row0 + W;
+  F8 v[4];
+  v[0] = load8<T>(y + (row0 + x0) * ldy + c);
+  v[1] = hasx ? load8<T>(y + (row0 + x0 + 1) * ldy + c) : zero8();
+  v[2] = hasy ? load8<T>(y + (row1 + x0) * ldy + c) : zero8();
+  v[3] = (hasx && hasy) ? load8<T>(y + (row1 + x0 + 1) * ldy + c) : zero8();
+  F8 o[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[u].v[j] = fmaxf(fmaf(v[u].v[j], sc[j], sh[j]), 0.f);
+  store8<T>(a + (row0 + x0) * lda + c, o[0]);
+  if (hasx) store8<T>(a + (row0 + x0 + 1) * lda + c, o[1]);
+  if (hasy) store8<T>(a + (row1 + x0) * lda + c, o[2]);
+  if (hasx && hasy) store8<T>(a + (row1 + x0 + 1) * lda + c, o[3]);
+  if (yo < Ho && xo < Wo) {
+    // the pooled value is the max of the ROUNDED activations (what a separate pool pass would read back)
+    F8 m;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      m.v[j] = fmaxf(fmaxf((float)(T)o[0].v[j], (float)(T)o[1].v[j]), fmaxf((float)(T)o[2].v[j], (float)(T)o[3].v[j]));
+    store8<T>(pl + (((size_t)n * Ho + yo) * Wo + xo) * ldp + c, m);
+  }
+}
+
 // Backward pass 1: block (64 channels x PIXB pixel slots); partial sums of dz and dz*xhat.
 constexpr int BWD_PIX_PER_BLOCK = 1024;
 
@@ -294,6 +341,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
   const int nv = C8 >> 3;
   const PixVec m(nv);
   if (m.ps >= m.PS) return;
+  if (inv_count <= 0.0) inv_count = 1.0 / sums[2 * C];   // data parallel: all-reduced pixel count appended to the sums
   const int64_t p0 = (int64_t)blockIdx.x * pixb;
   const int64_t p1 = p0 + pixb < npix ? p0 + pixb : npix;
   for (int vv = m.v; vv < nv; vv += m.nvl) {
@@ -373,7 +421,7 @@ int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* ou
 int mau_bn_finalize_train(const double* sums, double count, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
                           float* scale, float* shift, float* mean, float* invstd, int C, mau_stream_t stream) {
-  MAU_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0, "bn_finalize_train: bad arguments");
+  MAU_REQUIRE(sums && gamma && beta && scale && shift && mean && invstd && C > 0 && count >= 0, "bn_finalize_train: bad arguments");
   MAU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_train: running_mean/var must come together");
   MAU_LAUNCH(bn_finalize_train_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, gamma,
                      beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd, C);
@@ -419,6 +467,18 @@ int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* s
   return check_launch("bn_relu_apply_kernel");
 }
 
+int mau_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const float* shift, void* a, int lda, void* pooled,
+                           int ldp, int dtype, int N, int H, int W, int C, mau_stream_t stream) {
+  MAU_REQUIRE(y && a && pooled && scale && shift && N > 0 && H >= 2 && W >= 2 && C > 0, "bn_relu_apply_pool: bad arguments");
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(ldy % 8 == 0 && lda % 8 == 0 && ldp % 8 == 0 && ldy >= C8 && lda >= C8 && ldp >= C8, "bn_relu_apply_pool: bad ld");
+  MAU_REQUIRE((H + 1) / 2 <= 65535 && N <= 65535, "bn_relu_apply_pool: H/2 and N must fit a grid dimension");
+  dim3 grid(ceil_div(((W + 1) / 2) * (C8 / 8), 256), (H + 1) / 2, N);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bn_relu_apply_pool_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, scale,
+                                       shift, (T*)a, lda, (T*)pooled, ldp, H, W, C, C8));
+  return check_launch("bn_relu_apply_pool_kernel");
+}
+
 int mau_bn_bwd_rows(int64_t npix) { return ceil_div(npix, BWD_PIX_PER_BLOCK); }
 
 int mau_bn_relu_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale, const float* shift,
@@ -436,7 +496,7 @@ int mau_bn_relu_bwd_reduce(const void* da, int ldda, const void* y, int ldy, con
 int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const double* sums, double count, void* dy, int lddy,
                           int dtype, int64_t npix, int C, mau_stream_t stream) {
-  MAU_REQUIRE(da && y && dy && sums && npix > 0 && C > 0 && count > 0, "bn_relu_bwd_apply: bad arguments");
+  MAU_REQUIRE(da && y && dy && sums && npix > 0 && C > 0 && count >= 0, "bn_relu_bwd_apply: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && lddy >= C8, "bn_relu_bwd_apply: bad ld");
   // up to 64 pixels per thread and as few as 256 workgroups: this kernel's per-channel set-up (6 coefficient vectors,
@@ -446,12 +506,12 @@ int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, cons
   if (nt) {
     MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((bn_relu_bwd_apply_kernel<T, true>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
                                          (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, sums,
-                                         1.0 / count, (T*)dy, lddy, npix, C, C8, pixb));
+                                         count > 0 ? 1.0 / count : 0.0, (T*)dy, lddy, npix, C, C8, pixb));
     return check_launch("bn_relu_bwd_apply_kernel");
   }
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((bn_relu_bwd_apply_kernel<T, false>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, sums,
-                                               1.0 / count, (T*)dy, lddy, npix, C, C8, pixb));
+                                               count > 0 ? 1.0 / count : 0.0, (T*)dy, lddy, npix, C, C8, pixb));
   return check_launch("bn_relu_bwd_apply_kernel");
 }
 

@@ -450,6 +450,16 @@ static int launch_wgrad(const WgradP& p, hipStream_t st) {
 
 using namespace mau;
 
+template <typename T>
+__global__ void cast_f32_to_lp_kernel(const float* __restrict__ src, T* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (T)src[i];
+}
+static void cast_emb(const float* emb, void* ws, int n, bool f16v, hipStream_t st) {
+  if (f16v) MAU_LAUNCH(cast_f32_to_lp_kernel<f16>, dim3(ceil_div(n, 256)), dim3(256), 0, st, emb, (f16*)ws, n);
+  else MAU_LAUNCH(cast_f32_to_lp_kernel<bf16>, dim3(ceil_div(n, 256)), dim3(256), 0, st, emb, (bf16*)ws, n);
+}
+
 extern "C" {
 
 int mau_conv3x3_kc(int dtype) { return dtype == MAU_F32 ? PackKC<float>::value : PackKC<bf16>::value; }
@@ -470,69 +480,77 @@ int mau_conv3x3_pack_weights(const float* w, void* wf, void* wd, int dtype, int 
 }
 
 int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout) {
-  return dtype == MAU_BF16 ? conv_bf16_v2_num_pixel_tiles(N, H, W, Cout) : N * ceil_div(H, TH) * ceil_div(W, TW);
+  return dtype != MAU_F32 ? conv_bf16_v2_num_pixel_tiles(N, H, W, Cout) : N * ceil_div(H, TH) * ceil_div(W, TW);
 }
 
-__global__ void cast_f32_to_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = (bf16)src[i];
-}
-
-int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* wpk,
-                    const float* bias, const float* post_scale, const float* post_shift, void* y, int ldy, int Cout,
-                    float* slab, int dtype, int N, int H, int W, mau_stream_t stream) {
+int mau_conv3x3_fwd2(const void* x, int ldx, int C0, const void* x1, int ldx1, int C1, const float* emb, void* emb_ws, int E,
+                     const void* wpk, const float* bias, const float* post_scale, const float* post_shift, void* y, int ldy,
+                     int Cout, float* slab, int dtype, int N, int H, int W, mau_stream_t stream) {
   MAU_REQUIRE(x && wpk && y, "conv3x3_fwd: null pointer");
   MAU_REQUIRE(N > 0 && H > 0 && W > 0 && C0 > 0 && Cout > 0, "conv3x3_fwd: bad shape");
   MAU_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C0 && ldy >= Cout, "conv3x3_fwd: ld must be a multiple of 8 and >= C");
-  MAU_REQUIRE(E >= 0 && (E == 0 || (emb && E % 8 == 0 && C0 % 8 == 0)), "conv3x3_fwd: broadcast source needs E%%8==0 and C0%%8==0");
+  MAU_REQUIRE(C1 >= 0 && (C1 == 0 || (x1 && dtype != MAU_F32 && C0 % 16 == 0 && ldx1 % 8 == 0 && ldx1 >= C1 && ((uintptr_t)x1 % 16) == 0)),
+              "conv3x3_fwd: a second tensor source needs a 16-bit dtype, C0 %% 16 == 0 and an aligned x1 with ldx1 %% 8 == 0");
+  MAU_REQUIRE(E >= 0 && (E == 0 || (emb && E % 8 == 0 && (C0 + C1) % 8 == 0)), "conv3x3_fwd: broadcast source needs E%%8==0 and (C0+C1)%%8==0");
   MAU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wpk % 16) == 0, "conv3x3_fwd: pointers must be 16-byte aligned");
   MAU_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "conv3x3_fwd: post_scale and post_shift come together");
   ConvP p;
-  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.emb_lp = nullptr; p.E = E; p.w = wpk; p.bias = bias; p.post_scale = post_scale; p.post_shift = post_shift; p.y = y; p.ldy = ldy;
+  p.x = x; p.ldx = ldx; p.C0 = C0; p.x1 = C1 > 0 ? x1 : nullptr; p.ldx1 = C1 > 0 ? ldx1 : 0; p.C1 = C1;
+  p.emb = emb; p.emb_lp = nullptr; p.E = E; p.w = wpk; p.bias = bias; p.post_scale = post_scale; p.post_shift = post_shift; p.y = y; p.ldy = ldy;
   p.Cout = Cout; p.CoutPad = round_up(Cout, 64); p.slab = slab; p.N = N; p.H = H; p.W = W;
   p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
-  p.nChunks = ceil_div(C0 + E, mau_conv3x3_kc(dtype));
+  p.nChunks = ceil_div(C0 + C1 + E, mau_conv3x3_kc(dtype));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MAU_F32) return launch_conv<float>(p, st);
-  if (dtype == MAU_BF16) {
+  if (dtype == MAU_BF16 || dtype == MAU_F16) {
     if (E > 0) {
-      MAU_REQUIRE(emb_ws != nullptr && ((uintptr_t)emb_ws % 16) == 0, "conv3x3_fwd: bf16 broadcast source needs the (N,E) bf16 workspace emb_ws");
-      MAU_LAUNCH(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
+      MAU_REQUIRE(emb_ws != nullptr && ((uintptr_t)emb_ws % 16) == 0, "conv3x3_fwd: 16-bit broadcast source needs the (N,E) workspace emb_ws");
+      cast_emb(emb, emb_ws, N * E, dtype == MAU_F16, st);
       p.emb_lp = emb_ws;
     }
-    return launch_conv_bf16_v2(p, false, st);
+    return launch_conv_bf16_v2(p, dtype == MAU_F16, st);
   }
   set_error("bad dtype %d", dtype);
   return MAU_ERR_ARG;
 }
 
+int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* wpk,
+                    const float* bias, const float* post_scale, const float* post_shift, void* y, int ldy, int Cout,
+                    float* slab, int dtype, int N, int H, int W, mau_stream_t stream) {
+  return mau_conv3x3_fwd2(x, ldx, C0, nullptr, 0, 0, emb, emb_ws, E, wpk, bias, post_scale, post_shift, y, ldy, Cout, slab, dtype,
+                          N, H, W, stream);
+}
+
 int mau_conv3x3_wgrad_splits(int dtype, int N, int H, int W, int Cout, int Cin) {
-  return dtype == MAU_BF16 ? wgrad_bf16_v2_splits(N, H, W, Cout, Cin) : 1;
+  return dtype != MAU_F32 ? wgrad_bf16_v2_splits(N, H, W, Cout, Cin) : 1;
 }
 
 size_t mau_conv3x3_wgrad_acc_elems(int dtype, int N, int H, int W, int Cout, int Cin) {
   return (size_t)mau_conv3x3_wgrad_splits(dtype, N, H, W, Cout, Cin) * 9 * round_up(Cout, 64) * round_up(Cin, 64);
 }
 
-int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* dy, int lddy,
-                      int Cout, float* acc, int dtype, int N, int H, int W, mau_stream_t stream) {
+int mau_conv3x3_wgrad2(const void* x, int ldx, int C0, const void* x1, int ldx1, int C1, const float* emb, void* emb_ws, int E,
+                       const void* dy, int lddy, int Cout, float* acc, int dtype, int N, int H, int W, mau_stream_t stream) {
   MAU_REQUIRE(x && dy && acc, "conv3x3_wgrad: null pointer");
   MAU_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && ldx >= C0 && lddy >= Cout, "conv3x3_wgrad: bad ld");
-  MAU_REQUIRE(E >= 0 && (E == 0 || (emb && E % 8 == 0 && C0 % 8 == 0)), "conv3x3_wgrad: broadcast source needs E%%8==0 and C0%%8==0");
+  MAU_REQUIRE(C1 >= 0 && (C1 == 0 || (x1 && dtype != MAU_F32 && C0 % 8 == 0 && ldx1 % 8 == 0 && ldx1 >= C1 && ((uintptr_t)x1 % 16) == 0)),
+              "conv3x3_wgrad: a second tensor source needs a 16-bit dtype, C0 %% 8 == 0 and an aligned x1 with ldx1 %% 8 == 0");
+  MAU_REQUIRE(E >= 0 && (E == 0 || (emb && E % 8 == 0 && (C0 + C1) % 8 == 0)), "conv3x3_wgrad: broadcast source needs E%%8==0 and (C0+C1)%%8==0");
   MAU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0, "conv3x3_wgrad: pointers must be 16-byte aligned");
   WgradP p;
-  p.x = x; p.ldx = ldx; p.C0 = C0; p.emb = emb; p.emb_lp = nullptr; p.E = E; p.dy = dy; p.lddy = lddy; p.Cout = Cout;
-  p.CoutPad = round_up(Cout, 64); p.Cin = C0 + E; p.CinPad = round_up(C0 + E, 64); p.acc = acc;
+  p.x = x; p.ldx = ldx; p.C0 = C0; p.x1 = C1 > 0 ? x1 : nullptr; p.ldx1 = C1 > 0 ? ldx1 : 0; p.C1 = C1;
+  p.emb = emb; p.emb_lp = nullptr; p.E = E; p.dy = dy; p.lddy = lddy; p.Cout = Cout;
+  p.CoutPad = round_up(Cout, 64); p.Cin = C0 + C1 + E; p.CinPad = round_up(C0 + C1 + E, 64); p.acc = acc;
   p.N = N; p.H = H; p.W = W; p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
   p.nTiles = N * p.tilesX * p.tilesY;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MAU_BF16) {
+  if (dtype == MAU_BF16 || dtype == MAU_F16) {
     if (E > 0) {
-      MAU_REQUIRE(emb_ws != nullptr && ((uintptr_t)emb_ws % 16) == 0, "conv3x3_wgrad: bf16 broadcast source needs the (N,E) bf16 workspace emb_ws");
-      MAU_LAUNCH(cast_f32_to_bf16_kernel, dim3(ceil_div(N * E, 256)), dim3(256), 0, st, emb, (bf16*)emb_ws, N * E);
+      MAU_REQUIRE(emb_ws != nullptr && ((uintptr_t)emb_ws % 16) == 0, "conv3x3_wgrad: 16-bit broadcast source needs the (N,E) workspace emb_ws");
+      cast_emb(emb, emb_ws, N * E, dtype == MAU_F16, st);
       p.emb_lp = emb_ws;
     }
-    return launch_wgrad_bf16_v2(p, false, st);        // split-K partial slabs, plain stores (no memset needed)
+    return launch_wgrad_bf16_v2(p, dtype == MAU_F16, st);        // split-K partial slabs, plain stores (no memset needed)
   }
   MAU_REQUIRE(dtype == MAU_F32, "bad dtype %d", dtype);
   if (hipMemsetAsync(acc, 0, mau_conv3x3_wgrad_acc_elems(dtype, N, H, W, Cout, C0 + E) * sizeof(float), st) != hipSuccess) {
@@ -540,6 +558,11 @@ int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* em
     return MAU_ERR_HIP;
   }
   return launch_wgrad<float>(p, st);
+}
+
+int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* dy, int lddy,
+                      int Cout, float* acc, int dtype, int N, int H, int W, mau_stream_t stream) {
+  return mau_conv3x3_wgrad2(x, ldx, C0, nullptr, 0, 0, emb, emb_ws, E, dy, lddy, Cout, acc, dtype, N, H, W, stream);
 }
 
 int mau_conv3x3_unpack_wgrad(const float* acc, int nsplit, float* dw, int Cout, int Cin, mau_stream_t stream) {

@@ -92,7 +92,7 @@ struct Geo {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int BN, int MT, int NW, int EPI>
+template <int BN, int MT, int NW, int EPI, bool F16>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
   using G = Geo<BN, MT, NW>;
   constexpr int WN = G::WN, WM = G::WM, TH = G::TH, HPIX = G::HPIX, HALO_Q = G::HALO_Q, HALO_BYTES = G::HALO_BYTES;
@@ -105,9 +105,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
   const int wm = wave % WM, wn = wave / WM;
   const int i32 = perm32(lane & 31), h = lane >> 5;   // tile row (pixel / channel) this lane's operands come from
 
-  const bf16* __restrict__ xg = reinterpret_cast<const bf16*>(p.x);
-  const bf16* __restrict__ wg = reinterpret_cast<const bf16*>(p.w);
-  const bf16* zero = reinterpret_cast<const bf16*>(g_zero_page);
+  // (16-bit elements are only moved, never interpreted, outside the matrix core and the epilogue's conversion)
+  const unsigned short* __restrict__ xg = reinterpret_cast<const unsigned short*>(p.x);
+  const unsigned short* __restrict__ x1g = reinterpret_cast<const unsigned short*>(p.x1);
+  const unsigned short* __restrict__ wg = reinterpret_cast<const unsigned short*>(p.w);
+  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page);
 
   // ---- work items: XCD-aware order; a persistent workgroup walks I = blockIdx.x, +gridDim.x, ...
   // (gridDim.x is a multiple of 8, so a workgroup stays on one XCD's slice of the item list) ----
@@ -138,75 +140,78 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
   };
 
   // ---- per-lane DMA slots: the tile-independent part.  The address of a wave-DMA is computed WITHOUT
-  // control flow (selects only), so that the tap sequence of a stage stays one basic block and the
-  // compiler's waitcnt pass can count outstanding ds_reads instead of draining them. ----
+  // control flow (selects only), so that the tap sequence of a stage stays one basic block. ----
+  // Input channels come from up to two tensors and a broadcast vector (virtual concat: torch.cat([skip, up], 1) of the
+  // decoder, reference src/model.py:279-282, and fuse_embeddings :248-259, never materialised):
+  //   [0, C0) from x (pixel stride ldx) | [C0, C0 + C1) from x1 (ldx1) | [C0 + C1, C0 + C1 + E) from emb[n] | zero page.
+  // A stage is one 16-channel chunk; with two tensors C0 % 16 == 0, so the tensor a chunk reads is wave-uniform.
   int slot_hp[PER_WAVE];            // halo: pixel index inside the halo tile (or -1); weights: row = tap*BN + co
   int slot_c[PER_WAVE];             // 8 * logical 16-byte half
-  int s_limt[PER_WAVE];             // wave-uniform: channels [0, limt) come from the tensor source ...
-  int s_E[PER_WAVE];                // ... [C0, C0 + E) from the broadcast embedding, everything else from the zero page
-  size_t s_stride[PER_WAVE];        // elements per K chunk along the tensor source
   const size_t w_stage_stride = (size_t)9 * p.CoutPad * KC;
+  const int Ctot = p.C0 + p.C1;     // tensor channels; the broadcast embedding follows
 #pragma unroll
   for (int j = 0; j < PER_WAVE; ++j) {
     const int q = wave + j * NW;
     slot_hp[j] = -1;
     slot_c[j] = 0;
-    s_limt[j] = 0;
-    s_E[j] = 0;
-    s_stride[j] = 0;
     if (q < HALO_Q) {
       const int slot = q * 64 + lane;
       const int hp = slot >> 1, ph = slot & 1;
       slot_c[j] = 8 * (ph ^ halo_swz(hp % HS));
       slot_hp[j] = hp < HPIX ? hp : -1;
-      s_limt[j] = p.E == 0 ? p.ldx : p.C0;
-      s_E[j] = p.E;
-      s_stride[j] = KC;
     } else if (q < TOT_Q) {
       const int slot = (q - HALO_Q) * 64 + lane;
       const int row = slot >> 1, ph = slot & 1;
       slot_c[j] = 8 * (ph ^ ((row >> 3) & 1));
       slot_hp[j] = row;
-      s_limt[j] = 0x7fffffff;
-      s_stride[j] = w_stage_stride;
     }
   }
 
-  // source descriptors of the item being LOADED (constant over its stages); nullptr = zero page
-  const bf16* src_base[PER_WAVE];
-  const bf16* embn = nullptr;
+  // per-lane source offsets of the item being LOADED (constant over its stages); -1 = zero page
+  //   halo slot: linear pixel index (n*H + gy)*W + gx;   weight slot: element offset of the row inside a chunk's slab
+  int off32[PER_WAVE];
+  const unsigned short* embn = nullptr;
   auto setup = [&](const Item& it) {
-    embn = reinterpret_cast<const bf16*>(p.emb_lp) + (size_t)it.n * p.E;
+    embn = reinterpret_cast<const unsigned short*>(p.emb_lp) + (size_t)it.n * p.E;
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
       const int q = wave + j * NW;
-      src_base[j] = nullptr;
+      off32[j] = -1;
       if (q < HALO_Q) {
         const int hp = slot_hp[j];
         if (hp >= 0) {
           const int gy = it.ty0 + hp / HS - 1, gx = it.tx0 + hp % HS - 1;
-          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-            src_base[j] = xg + ((size_t)(it.n * p.H + gy) * p.W + gx) * (size_t)p.ldx + slot_c[j];
+          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) off32[j] = (it.n * p.H + gy) * p.W + gx;
         }
       } else if (q < TOT_Q) {
         const int row = slot_hp[j];
         // (the packed rows are pre-permuted: row nt*32 + i of a 64-channel block holds output channel 2*i + nt, so the
         // two accumulator tiles of a lane carry ADJACENT channels -- pack_weights_kernel, conv3x3.hip)
         const int tap = row / BN, co = row % BN;
-        src_base[j] = wg + ((size_t)tap * p.CoutPad + it.co0 + co) * KC + slot_c[j];
+        off32[j] = (tap * p.CoutPad + it.co0 + co) * KC + slot_c[j];
       }
     }
   };
-  // one wave-DMA (1 KiB) of a stage; j is a compile-time constant after unrolling
+  // one wave-DMA (1 KiB) of a stage; j is a compile-time constant after unrolling.  Everything that depends only on
+  // (slot kind, chunk) is wave-uniform and computed on the scalar unit.
   auto issue_slot = [&](int j, int stage, int chunk) {
     const int q = wave + j * NW;                      // wave-uniform
-    const int c = chunk * KC + slot_c[j];
-    const bool valid = src_base[j] != nullptr;
-    const bf16* pt = src_base[j] + (size_t)chunk * s_stride[j];
-    const bf16* pe = embn + (c - p.C0);
-    const bool is_t = valid & (c < s_limt[j]);
-    const bool is_e = valid & ((unsigned)(c - p.C0) < (unsigned)s_E[j]);
-    const bf16* src = is_t ? pt : (is_e ? pe : zero);
+    const bool halo = q < HALO_Q;
+    const int c0 = chunk * KC;
+    const bool second = p.C1 > 0 && c0 >= p.C0;
+    const unsigned short* ub = halo ? (second ? x1g : xg) : wg + (size_t)chunk * w_stage_stride;
+    const unsigned um = halo ? (unsigned)(second ? p.ldx1 : p.ldx) : 1u;
+    const int ua = halo ? c0 - (second ? p.C0 : 0) : 0;
+    const int ulim = !halo ? 0x7fffffff
+                           : (second ? (p.E == 0 ? p.C0 + p.ldx1 : Ctot) : ((p.C1 == 0 && p.E == 0) ? p.ldx : p.C0));
+    const int c = c0 + slot_c[j];
+    const int add = halo ? ua + slot_c[j] : 0;
+    const bool valid = off32[j] >= 0;
+    const unsigned short* pt = ub + ((size_t)(unsigned)off32[j] * um + (size_t)add);
+    const unsigned short* pe = embn + (c - Ctot);
+    const bool is_t = valid & (c < ulim);
+    const bool is_e = valid & halo & ((unsigned)(c - Ctot) < (unsigned)p.E);
+    const unsigned short* src = is_t ? pt : (is_e ? pe : zero);
     __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + stage * STAGE + q * 1024), 16, 0, 0);
   };
   auto issue = [&](int stage, int chunk) {
@@ -237,8 +242,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
   setup(cur);
   issue(0, 0);
   int stage = 0;
-  bf16* __restrict__ yg = reinterpret_cast<bf16*>(p.y);
+  unsigned short* __restrict__ yg = reinterpret_cast<unsigned short*>(p.y);
 
+  bool stores_behind = false;      // (wave-uniform) the previous item's epilogue issued exactly its 4 * MT output stores
   while (true) {
     const int In = next_valid(I + gridDim.x, nxt);
     f32x16 acc[MT][2];
@@ -253,7 +259,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     // everyone is done with the buffer that is refilled next) -> issue the following stage, which may
     // already belong to the NEXT work item (cross-tile pipelining) -> multiply. ----
     for (int chunk = 0; chunk < p.nChunks; ++chunk) {
-      wait_vmcnt<0>();
+      // This wave's DMAs of the stage must have landed.  After an interior item's epilogue the 4 * MT output stores (and
+      // the statistics row) were issued AFTER those DMAs: the vector-memory counter retires in issue order, so waiting
+      // until at most 4 * MT operations are outstanding covers the DMAs without waiting out the stores' HBM write
+      // round trip (with vmcnt(0) every item of a short-K layer paid it: -21 % on the level-0 layers).
+#ifndef MAU_CONV_NO_COUNTED_EPI
+      if (chunk == 0 && stores_behind) wait_vmcnt<4 * MT>();
+      else
+#endif
+        wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       // next stage: the following chunk of this item, or chunk 0 of the next item (cross-tile pipelining);
       // after the very last stage chunk 0 of the current item is re-fetched into the idle buffer (nobody reads it)
@@ -277,8 +291,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     if constexpr ((T) < 8) fetch_tap<((T) < 8 ? (T) + 1 : 0), BN, MT>(fb[cs ^ 1], fa[cs ^ 1], b0a, b1a, aa); \
     land<((T) < 8 ? 2 + MT : 0), MT>(fb[cs], fa[cs]);                                 \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                               \
-      acc[mt][0] = mfma32(fa[cs][mt], fb[cs][0], acc[mt][0]);                         \
-      acc[mt][1] = mfma32(fa[cs][mt], fb[cs][1], acc[mt][1]);                         \
+      acc[mt][0] = mfma16<F16>(fa[cs][mt], fb[cs][0], acc[mt][0]);                         \
+      acc[mt][1] = mfma16<F16>(fa[cs][mt], fb[cs][1], acc[mt][1]);                         \
     }                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                \
     if constexpr ((T) < PER_WAVE) {                                                   \
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
               q2[1] = fmaf(v1, v1, q2[1]);
             }
             const f32x2 v = {v0, v1};
-            lds_write_b32<k * 128>(wbase[g], pack_bf16x2(v));
+            lds_write_b32<k * 128>(wbase[g], pack_lp2<F16>(v));
           });
         }
       };
@@ -389,18 +403,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
       }
     }
     if (In < 0) break;
+    stores_behind = full && cur.co0 + wn * 64 + 64 <= p.ldy;     // every lane stored, 4 * MT store instructions per wave
     cur = nxt;
     I = In;
   }
   wait_vmcnt<0>();                                     // the idle re-fetch of the last stage must land before the LDS is released
 }
 
-template <int BN, int MT, int NW, int EPI>
+template <int BN, int MT, int NW, int EPI, bool F16>
 static int launch(const ConvP& p, hipStream_t st) {
   using G = Geo<BN, MT, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, MT, NW, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     attr_set = true;
   }
@@ -408,7 +423,7 @@ static int launch(const ConvP& p, hipStream_t st) {
   ConvP q = p;
   q.tilesX = tilesX;
   q.tilesY = tilesY;
-  q.nChunks = ceil_div(p.C0 + p.E, KC);
+  q.nChunks = ceil_div(p.C0 + p.C1 + p.E, KC);
   const int nPixTiles = p.N * tilesX * tilesY;
   const int nCt = p.CoutPad / BN;
   const int nItems = round_up(nPixTiles, 8) * nCt;
@@ -416,7 +431,7 @@ static int launch(const ConvP& p, hipStream_t st) {
   const int per_cu = (int)((160 * 1024) / G::LDS) >= 2 && NW == 4 ? 2 : 1;
   int grid = 256 * per_cu;
   if (grid > nItems) grid = nItems;                    // nItems is a multiple of 8, and so is 256*per_cu
-  MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+  MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
   return check_launch("conv3x3_bf16_kernel");
 }
 
@@ -454,11 +469,15 @@ int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   return wm * N * ceil_div(H, th) * ceil_div(W, v2::TW);
 }
 
+template <int BN, int MT, int NW, bool F16>
+static int launch_epi2(const ConvP& p, hipStream_t st) {
+  if (p.post_scale != nullptr) return v2::launch<BN, MT, NW, v2::EPI_POST, F16>(p, st);      // (a post-affine launch carries no slab)
+  if (p.slab != nullptr) return v2::launch<BN, MT, NW, v2::EPI_STATS, F16>(p, st);
+  return v2::launch<BN, MT, NW, v2::EPI_PLAIN, F16>(p, st);
+}
 template <int BN, int MT, int NW>
-static int launch_epi(const ConvP& p, hipStream_t st) {
-  if (p.post_scale != nullptr) return v2::launch<BN, MT, NW, v2::EPI_POST>(p, st);      // (a post-affine launch carries no slab)
-  if (p.slab != nullptr) return v2::launch<BN, MT, NW, v2::EPI_STATS>(p, st);
-  return v2::launch<BN, MT, NW, v2::EPI_PLAIN>(p, st);
+static int launch_epi(const ConvP& p, bool f16, hipStream_t st) {
+  return f16 ? launch_epi2<BN, MT, NW, true>(p, st) : launch_epi2<BN, MT, NW, false>(p, st);
 }
 
 int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
@@ -467,8 +486,8 @@ int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
     return MAU_ERR_ARG;
   }
   const int th = v2::tile_height(p.CoutPad, p.N, p.H, p.W);
-  if (p.CoutPad % 128 == 0) return th == 32 ? launch_epi<128, 4, 8>(p, st) : launch_epi<128, 2, 8>(p, st);
-  return th == 32 ? launch_epi<64, 2, 8>(p, st) : launch_epi<64, 2, 4>(p, st);
+  if (p.CoutPad % 128 == 0) return th == 32 ? launch_epi<128, 4, 8>(p, f16, st) : launch_epi<128, 2, 8>(p, f16, st);
+  return th == 32 ? launch_epi<64, 2, 8>(p, f16, st) : launch_epi<64, 2, 4>(p, f16, st);
 }
 
 }  // namespace mau

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
   const int wco = wave % WCO, wci = (wave / WCO) & 1, kg = wave / (2 * WCO);
   const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
   const unsigned short* __restrict__ xg = reinterpret_cast<const unsigned short*>(p.x);
+  const unsigned short* __restrict__ x1g = reinterpret_cast<const unsigned short*>(p.x1);
   const unsigned short* __restrict__ dyg = reinterpret_cast<const unsigned short*>(p.dy);
   const unsigned short* __restrict__ emb = reinterpret_cast<const unsigned short*>(p.emb_lp);
   const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page);
@@ -135,12 +136,12 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
   static_assert(DY_Q % NW == 0, "dY / halo slots must split at a compile-time j");
   constexpr int DY_J = DY_Q / NW;
   int s_ry[PER_WAVE], s_rx[PER_WAVE], s_c[PER_WAVE];   // pixel offset inside the tile (halo: -1..), first channel of the 16-byte chunk
-  bool s_t[PER_WAVE], s_e[PER_WAVE];                   // source class: tensor (dY or X) / X broadcast embedding / neither = zero page
+  bool s_t[PER_WAVE], s_t2[PER_WAVE], s_e[PER_WAVE];   // source class: tensor (dY or X) / second X tensor / X broadcast embedding / none = zero page
 #pragma unroll
   for (int j = 0; j < PER_WAVE; ++j) {
     const int q = wave + j * NW;
     s_ry[j] = s_rx[j] = s_c[j] = 0;
-    s_t[j] = s_e[j] = false;
+    s_t[j] = s_t2[j] = s_e[j] = false;
     if (j < DY_J) {
       const int slot = q * 64 + lane;
       const int row = slot / DY_CPR, pc = slot % DY_CPR;
@@ -157,8 +158,10 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
       s_ry[j] = row / HW_ - 1;
       s_rx[j] = row % HW_ - 1;
       s_c[j] = c;
-      s_t[j] = row < HALO && (c < p.C0 || (p.E == 0 && c < p.ldx));
-      s_e[j] = row < HALO && !s_t[j] && c < p.C0 + p.E;
+      // input channels: [0, C0) from x | [C0, C0 + C1) from x1 (virtual concat) | then E broadcast channels | zero
+      s_t[j] = row < HALO && (c < p.C0 || (p.C1 == 0 && p.E == 0 && c < p.ldx));
+      s_t2[j] = row < HALO && c >= p.C0 && c < p.C0 + p.C1;
+      s_e[j] = row < HALO && c >= p.C0 + p.C1 && c < p.C0 + p.C1 + p.E;
     }
   }
   // one wave-DMA (1 KiB); (n, ty0, tx0) wave-uniform; predicates and selects only (as conv3x3_bf16.hip's issue_slot)
@@ -174,10 +177,15 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
       const unsigned short* pt = dyg + pix * (size_t)p.lddy + s_c[j];
       src = is_t ? pt : zero;
     } else {
-      const unsigned short* pt = xg + pix * (size_t)p.ldx + s_c[j];
-      const unsigned short* pe = emb + (n * p.E + (s_c[j] - p.C0));
+      const bool is_t2 = inb & s_t2[j];
+      // one 64-bit multiply-add on selected operands serves both tensors
+      const unsigned short* tb = is_t2 ? x1g : xg;
+      const size_t tld = is_t2 ? (size_t)p.ldx1 : (size_t)p.ldx;
+      const int tc = is_t2 ? s_c[j] - p.C0 : s_c[j];
+      const unsigned short* pt = tb + (pix * tld + tc);
+      const unsigned short* pe = emb + (n * p.E + (s_c[j] - p.C0 - p.C1));
       const bool is_e = inb & s_e[j];
-      src = is_t ? pt : (is_e ? pe : zero);
+      src = (is_t | is_t2) ? pt : (is_e ? pe : zero);
     }
     __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + stage * STRIDE + q * 1024), 16, 0, 0);
   };

@@ -13,10 +13,18 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// 16-bit operand fragments travel as raw 128-bit registers (typed bf16x8); F16 selects how the matrix core reads them
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 struct ConvP {
   const void* x;
   int ldx, C0;
+  const void* x1;       // optional second tensor source: input channels [C0, C0 + C1) (virtual channel concat), else nullptr
+  int ldx1, C1;
   const float* emb;     // fp32 (N,E) broadcast source (float kernels)
   const void* emb_lp;   // the same in the activation dtype (bf16 kernel), filled by the C entry point
   int E;
@@ -40,6 +48,8 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 struct WgradP {
   const void* x;
   int ldx, C0;
+  const void* x1;       // optional second tensor source (channels [C0, C0 + C1) of the convolution's input)
+  int ldx1, C1;
   const float* emb;
   const void* emb_lp;   // embedding in the activation dtype (bf16 kernel)
   int E;

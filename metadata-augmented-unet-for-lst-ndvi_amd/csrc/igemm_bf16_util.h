@@ -49,6 +49,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // two fp32 -> one dword of two bf16 (round to nearest even): v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16x2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> one dword of two 16-bit values of the activation type (round to nearest even)
+template <bool F16>
+__device__ __forceinline__ unsigned pack_lp2(f32x2 v) {
+  if constexpr (F16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  else return pack_bf16x2(v);
+}
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int OFF>
 __device__ __forceinline__ u32x4 lds_read_u128(unsigned addr) {

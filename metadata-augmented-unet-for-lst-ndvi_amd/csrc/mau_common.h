@@ -6,7 +6,9 @@
 #include "../../include/mau_hip.h"
 
 typedef __bf16 bf16;
+typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -63,6 +65,14 @@ __device__ __forceinline__ F8 load8<bf16>(const bf16* p) {
   for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
   return r;
 }
+template <>
+__device__ __forceinline__ F8 load8<f16>(const f16* p) {
+  F8 r;
+  f16x8 a = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+  return r;
+}
 template <typename T>
 __device__ __forceinline__ void store8(T* p, const F8& r);
 template <>
@@ -82,6 +92,14 @@ __device__ __forceinline__ void store8<bf16>(bf16* p, const F8& r) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = (bf16)r.v[i];
   *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+template <>
+__device__ __forceinline__ void store8<f16>(f16* p, const F8& r) {
+  f16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (f16)r.v[i];
+  *reinterpret_cast<f16x8*>(p) = a;
 }
 
 // non-temporal (streaming) variants for data touched exactly once by a kernel
@@ -107,6 +125,14 @@ __device__ __forceinline__ F8 load8_nt<bf16>(const bf16* p) {
   for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
   return r;
 }
+template <>
+__device__ __forceinline__ F8 load8_nt<f16>(const f16* p) {
+  F8 r;
+  const f16x8 a = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+  return r;
+}
 template <typename T>
 __device__ __forceinline__ void store8_nt(T* p, const F8& r);
 template <>
@@ -126,6 +152,14 @@ __device__ __forceinline__ void store8_nt<bf16>(bf16* p, const F8& r) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = (bf16)r.v[i];
   __builtin_nontemporal_store(a, reinterpret_cast<bf16x8*>(p));
+}
+
+template <>
+__device__ __forceinline__ void store8_nt<f16>(f16* p, const F8& r) {
+  f16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (f16)r.v[i];
+  __builtin_nontemporal_store(a, reinterpret_cast<f16x8*>(p));
 }
 
 __device__ __forceinline__ F8 zero8() {
@@ -157,6 +191,9 @@ static inline int stream_grid(int64_t work_items, int block) {
       __VA_ARGS__;                                  \
     } else if ((dtype) == MAU_BF16) {               \
       using T = bf16;                               \
+      __VA_ARGS__;                                  \
+    } else if ((dtype) == MAU_F16) {                \
+      using T = f16;                                \
       __VA_ARGS__;                                  \
     } else {                                        \
       ::mau::set_error("bad dtype %d", (int)dtype); \

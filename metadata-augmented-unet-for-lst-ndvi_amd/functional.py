@@ -1,8 +1,8 @@
 """Autograd functions of the hot path; every forward/backward is a call into libmau_hip.so.
 
 Internal activations are "NHWC-ld" tensors: ``torch`` tensors of shape (N, H, W, ld) with
-``ld = roundup(C, 8)``, dtype ``torch.bfloat16`` (throughput mode) or ``torch.float32``
-(parity mode); channels [C, ld) are always zero.  PyTorch only provides device
+``ld = roundup(C, 8)``, dtype ``torch.bfloat16`` (throughput mode), ``torch.float16`` (the same
+kernels on fp16 operands, inference) or ``torch.float32`` (parity mode); channels [C, ld) are always zero.  PyTorch only provides device
 memory, streams and the autograd graph; no arithmetic of the path runs in torch.
 
 Reference: src/model.py (VGGBlock :9-21, pool :218, up/_upsample_match :219,243-246,
@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import MAU_BF16, MAU_F32, call, lib
+from ._lib import MAU_BF16, MAU_F16, MAU_F32, call, lib
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -32,6 +32,8 @@ def dtype_code(dt: torch.dtype) -> int:
         return MAU_F32
     if dt == torch.bfloat16:
         return MAU_BF16
+    if dt == torch.float16:
+        return MAU_F16
     raise TypeError(f"unsupported activation dtype {dt}")
 
 
@@ -88,22 +90,54 @@ class Act:
 # --------------------------------------------------------------------------- #
 # weight packing
 # --------------------------------------------------------------------------- #
+_DT = {MAU_F32: torch.float32, MAU_BF16: torch.bfloat16, MAU_F16: torch.float16}
+_GENERATION = [0]
+
+
+def mark_params_updated(*_args, **_kwargs):
+    """Invalidate every cached weight pack.  Registered as a GLOBAL optimizer-step post hook (below), so any
+    ``torch.optim`` step -- including the fused AdamW kernel, which updates parameters in place WITHOUT bumping
+    ``Tensor._version`` -- is followed by a re-pack on the next forward.  Call it by hand after writing to a
+    parameter through ``.data`` or a raw pointer (in-place tensor ops, ``copy_`` and ``load_state_dict`` bump
+    ``_version`` and are detected by themselves)."""
+    _GENERATION[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_step_hook  # noqa: E402
+
+_reg_step_hook(mark_params_updated)
+
+
 def pack_conv_weights(w: torch.Tensor, code: int, forward: bool = True, dgrad: bool = False):
     """OIHW fp32 master weights -> (forward pack, data-gradient pack) in the activation dtype, ONE launch.
 
-    Deliberately NOT cached across calls: there is no reliable change signal for a parameter -- the fused
-    AdamW kernel (``torch.optim.AdamW(fused=True)``) updates parameters in place WITHOUT bumping
-    ``Tensor._version`` -- and a stale pack silently trains/infers with old weights.  Packing the whole
-    network costs ~0.06 ms per step (128 MB read, 2 x 64 MB written).
+    The packs are cached on the parameter and keyed by (optimizer-step generation, ``w._version``, storage address,
+    dtype): they are rebuilt once per optimizer step (``mark_params_updated``), not once per forward.  A version-only
+    key served stale weights from step 2 on with fused AdamW (``tests/test_gpu_model.py::
+    test_multi_step_training_tracks_oracle`` is the regression test); the generation counter closes that hole.
     """
     cout, cin = w.shape[0], w.shape[1]
-    dt = torch.float32 if code == MAU_F32 else torch.bfloat16
-    src = w.detach()
-    wf = torch.empty(lib.mau_conv3x3_packed_elems(code, cout, cin), dtype=dt, device=w.device) if forward else None
-    wd = torch.empty(lib.mau_conv3x3_packed_elems(code, cin, cout), dtype=dt, device=w.device) if dgrad else None
-    call("mau_conv3x3_pack_weights", src.data_ptr(), wf.data_ptr() if forward else None, wd.data_ptr() if dgrad else None,
-         code, cout, cin, _stream())
-    return wf, wd
+    key = (_GENERATION[0], w._version, w.data_ptr(), code)
+    cache = getattr(w, "_mau_pack", None)
+    if cache is None or cache[0] != key:
+        cache = [key, None, None]
+        try:
+            w._mau_pack = cache
+        except (AttributeError, RuntimeError):      # a tensor that refuses attributes: no caching
+            pass
+    need_f, need_d = forward and cache[1] is None, dgrad and cache[2] is None
+    if need_f or need_d:
+        dt = _DT[code]
+        src = w.detach()
+        wf = torch.empty(lib.mau_conv3x3_packed_elems(code, cout, cin), dtype=dt, device=w.device) if need_f else None
+        wd = torch.empty(lib.mau_conv3x3_packed_elems(code, cin, cout), dtype=dt, device=w.device) if need_d else None
+        call("mau_conv3x3_pack_weights", src.data_ptr(), wf.data_ptr() if need_f else None, wd.data_ptr() if need_d else None,
+             code, cout, cin, _stream())
+        if need_f:
+            cache[1] = wf
+        if need_d:
+            cache[2] = wd
+    return (cache[1] if forward else None), (cache[2] if dgrad else None)
 
 
 # --------------------------------------------------------------------------- #
@@ -148,13 +182,15 @@ def to_nchw(a: Act) -> torch.Tensor:
 class BNState:
     """Non-tensor configuration of one conv-bn-relu (module buffers are passed as tensors)."""
     training: bool
-    C0: int                               # logical channels of the tensor source
+    C0: int                               # logical channels of the (first) tensor source
     momentum: float = BN_MOMENTUM
     eps: float = BN_EPS
     group: object = None                  # torch.distributed process group for SyncBN (None = local BN)
     world: int = 1
     grad_enabled: bool = True             # torch.is_grad_enabled() at call time (invisible inside Function.forward)
     frozen: object = None                 # dict of a frozen inference session (packed weights, scale, shift) or None
+    C1: int = 0                           # logical channels of the second tensor source (virtual concat), 0 = none
+    pool: bool = False                    # also return maxpool2x2(output) (encoder blocks: skip + next level)
 
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
@@ -174,101 +210,124 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     return s
 
 
+def _conv_fwd(x, x1, st, emb, emb_ws, E, wpk, bias, post, y, Cout, slab, code, N, H, W, stream):
+    """One launch of the implicit-GEMM convolution over cat([x, x1, broadcast(emb)], channels)."""
+    scale, shift = post if post is not None else (None, None)
+    call("mau_conv3x3_fwd2", x.data_ptr(), _ld(x), st.C0, x1.data_ptr() if x1 is not None else None,
+         _ld(x1) if x1 is not None else 0, st.C1 if x1 is not None else 0, emb.data_ptr() if E else None,
+         emb_ws.data_ptr() if E else None, E, wpk.data_ptr(), bias.data_ptr() if bias is not None else None,
+         scale.data_ptr() if scale is not None else None, shift.data_ptr() if shift is not None else None,
+         y.data_ptr(), _ld(y), Cout, slab.data_ptr() if slab is not None else None, code, N, H, W, stream)
+
+
 class ConvBNReLU(torch.autograd.Function):
-    """relu(bn(conv3x3(cat([x, broadcast(emb)])))) -- one half of VGGBlock.forward (src/model.py:18-21)."""
+    """relu(bn(conv3x3(cat([x, x1, broadcast(emb)], 1)))) -- one half of VGGBlock.forward (src/model.py:18-21) with the
+    decoder's channel concat (src/model.py:279-282) and fuse_embeddings (:248-259) as loader sources, never materialised.
+    With ``st.pool`` the second output is nn.MaxPool2d(2,2) of the first (src/model.py:268-271), written in the same pass."""
 
     @staticmethod
-    def forward(ctx, x, emb, weight, bias, gamma, beta, rmean, rvar, nbt, st: BNState):
+    def forward(ctx, x, x1, emb, weight, bias, gamma, beta, rmean, rvar, nbt, st: BNState):
         _require_cuda(x, "conv3x3")
         x = _as_nhwc(x)
+        if x1 is not None:
+            x1 = _as_nhwc(x1)
         N, H, W, _ = x.shape
         code = dtype_code(x.dtype)
         dev = x.device
         Cout, Cin = weight.shape[0], weight.shape[1]
         E = 0 if emb is None else emb.shape[1]
-        if st.C0 + E != Cin:
-            raise RuntimeError(f"conv3x3: input has {st.C0}+{E} channels, weight expects {Cin}")
+        C1 = st.C1 if x1 is not None else 0
+        if st.C0 + C1 + E != Cin:
+            raise RuntimeError(f"conv3x3: input has {st.C0}+{C1}+{E} channels, weight expects {Cin}")
         if emb is not None:
             emb = emb.contiguous().float()
-        ldx = _ld(x)
         ldy = pad8(Cout)
         stream = _stream()
-        inference = (not st.training) and (not st.grad_enabled or not any(ctx.needs_input_grad))
-        if inference and st.frozen is not None:
-            # frozen session (UrbanPredictor.freeze_inference): the packed weights and the folded BatchNorm coefficients
-            # were computed once; per call only the convolution itself runs
-            fz = st.frozen
-            if "wf" not in fz or fz["wf"].dtype != x.dtype:
-                fz["wf"] = pack_conv_weights(weight, code, forward=True, dgrad=False)[0]
-                fz["scale"], fz["shift"] = torch.empty(Cout, dtype=torch.float32, device=dev), torch.empty(Cout, dtype=torch.float32, device=dev)
-                call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
-                     st.eps, fz["scale"].data_ptr(), fz["shift"].data_ptr(), None, None, Cout, stream)
-            y = torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
-            emb_ws = torch.empty((N, E), dtype=x.dtype, device=dev) if E else None
-            call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,
-                 emb_ws.data_ptr() if E else None, E, fz["wf"].data_ptr(), bias.data_ptr(), fz["scale"].data_ptr(),
-                 fz["shift"].data_ptr(), y.data_ptr(), ldy, Cout, None, code, N, H, W, stream)
-            return y
-        need_dgrad_pack = st.grad_enabled and (ctx.needs_input_grad[0] or (E > 0 and ctx.needs_input_grad[1]))
-        wf, wd = pack_conv_weights(weight, code, forward=True, dgrad=need_dgrad_pack)
+        needs = ctx.needs_input_grad
+        inference = (not st.training) and (not st.grad_enabled or not any(needs))
+        emb_ws = torch.empty((N, E), dtype=x.dtype, device=dev) if E else None
         y = torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
+
+        def pooled_of(a):
+            pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
+            call("mau_maxpool2x2_fwd", a.data_ptr(), ldy, pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
+            return pl
+
+        if inference:
+            # eval-mode BN + ReLU are a fixed per-channel affine map -> folded into the conv epilogue.  In a frozen
+            # session (UrbanPredictor.freeze_inference) the packed weights and the folded coefficients are computed once.
+            fz = st.frozen if st.frozen is not None else {}
+            if "wf" not in fz or fz["wf"].dtype != x.dtype:
+                fz["wf"] = pack_conv_weights(weight, code, forward=True, dgrad=False)[0]
+                fz["scale"], fz["shift"] = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+                call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
+                     st.eps, fz["scale"].data_ptr(), fz["shift"].data_ptr(), None, None, Cout, stream)
+            _conv_fwd(x, x1, st, emb, emb_ws, E, fz["wf"], bias, (fz["scale"], fz["shift"]), y, Cout, None, code, N, H, W, stream)
+            ctx.mark_non_differentiable(y)
+            if st.pool:
+                pl = pooled_of(y)
+                ctx.mark_non_differentiable(pl)
+                return y, pl
+            return y
+        need_dx = needs[0] or (x1 is not None and needs[1]) or (E > 0 and needs[2])
+        wf, wd = pack_conv_weights(weight, code, forward=True, dgrad=st.grad_enabled and need_dx)
         scale, shift = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
         mean, invstd = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
         npix = N * H * W
-        emb_ws = torch.empty((N, E), dtype=x.dtype, device=dev) if E else None
         if st.training:
             tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W, Cout)
             cpad = (Cout + 63) // 64 * 64
             slab = torch.empty((tiles, 2 * cpad), **f32)
-            call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,
-                 emb_ws.data_ptr() if E else None, E, wf.data_ptr(),
-                 bias.data_ptr(), None, None, y.data_ptr(), ldy, Cout, slab.data_ptr(), code, N, H, W, stream)
-            count = float(npix * st.world)
+            _conv_fwd(x, x1, st, emb, emb_ws, E, wf, bias, None, y, Cout, slab, code, N, H, W, stream)
             nbt_ptr = nbt.data_ptr() if nbt is not None else None
             if st.group is None:
                 # single GPU: slab -> fp64 partials -> (second level + finalize) in two launches
                 ws = torch.empty(lib.mau_bn_stats_ws_elems(tiles, Cout), dtype=torch.float64, device=dev)
-                call("mau_bn_stats_finalize_train", slab.data_ptr(), tiles, count, gamma.data_ptr(), beta.data_ptr(),
+                call("mau_bn_stats_finalize_train", slab.data_ptr(), tiles, float(npix), gamma.data_ptr(), beta.data_ptr(),
                      rmean.data_ptr(), rvar.data_ptr(), nbt_ptr, st.momentum, st.eps, scale.data_ptr(), shift.data_ptr(),
                      mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), Cout, stream)
             else:
-                sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)          # [sum(y) | sum(y^2)]
+                # SyncBN: ONE collective per layer carries [sum(y) | sum(y^2) | local pixel count]; the count is summed
+                # with the statistics, so ranks with different local batch sizes still agree on the global moments
+                sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
                 ws = torch.empty(2 * lib.mau_reduce_rows_ws_elems(tiles, Cout), dtype=torch.float64, device=dev)
                 call("mau_reduce_rows_f64", slab.data_ptr(), tiles, Cout, 2 * cpad, sums.data_ptr(), ws.data_ptr(), stream)
                 call("mau_reduce_rows_f64", slab.data_ptr() + 4 * cpad, tiles, Cout, 2 * cpad, sums.data_ptr() + 8 * Cout,
                      ws.data_ptr() + 4 * ws.numel(), stream)
-                _all_reduce_(sums, st)                                                  # SyncBN: one collective per layer
-                call("mau_bn_finalize_train", sums.data_ptr(), count, gamma.data_ptr(), beta.data_ptr(),
+                sums[2 * Cout] = float(npix)
+                _all_reduce_(sums, st)
+                call("mau_bn_finalize_train", sums.data_ptr(), 0.0, gamma.data_ptr(), beta.data_ptr(),
                      rmean.data_ptr(), rvar.data_ptr(), nbt_ptr, st.momentum, st.eps, scale.data_ptr(), shift.data_ptr(),
                      mean.data_ptr(), invstd.data_ptr(), Cout, stream)
         else:
             call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                  st.eps, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cout, stream)
-            if not st.grad_enabled or not any(ctx.needs_input_grad):
-                # inference: eval-mode BN + ReLU are a fixed per-channel affine map -> folded into the conv epilogue
-                call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,
-                     emb_ws.data_ptr() if E else None, E, wf.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                     y.data_ptr(), ldy, Cout, None, code, N, H, W, stream)
-                return y
-            call("mau_conv3x3_fwd", x.data_ptr(), ldx, st.C0, emb.data_ptr() if E else None,
-                 emb_ws.data_ptr() if E else None, E, wf.data_ptr(),
-                 bias.data_ptr(), None, None, y.data_ptr(), ldy, Cout, None, code, N, H, W, stream)
+            _conv_fwd(x, x1, st, emb, emb_ws, E, wf, bias, None, y, Cout, None, code, N, H, W, stream)
         a = torch.empty_like(y)
-        call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), ldy, code,
-             npix, Cout, stream)
+        pl = None
+        if st.pool and H >= 2 and W >= 2:
+            pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
+            call("mau_bn_relu_apply_pool", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), ldy,
+                 pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
+        else:
+            call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), ldy, code,
+                 npix, Cout, stream)
         ctx.st = st
         ctx.E = E
+        ctx.C1 = C1
         ctx.wd = wd                           # data-gradient pack of THIS forward's weights
-        ctx.save_for_backward(x, emb, weight, y, scale, shift, mean, invstd)
+        ctx.pooled = pl is not None
+        ctx.save_for_backward(x, x1, emb, weight, y, scale, shift, mean, invstd, a if pl is not None else None)
+        if st.pool:
+            return a, pl
         return a
 
     @staticmethod
-    def backward(ctx, da):
-        x, emb, weight, y, scale, shift, mean, invstd = ctx.saved_tensors
+    def backward(ctx, da, dpl=None):
+        x, x1, emb, weight, y, scale, shift, mean, invstd, a = ctx.saved_tensors
         st: BNState = ctx.st
-        E = ctx.E
-        da = _as_nhwc(da)
+        E, C1 = ctx.E, ctx.C1
         N, H, W, ldy = y.shape
         code = dtype_code(y.dtype)
         dev = y.device
@@ -276,31 +335,49 @@ class ConvBNReLU(torch.autograd.Function):
         npix = N * H * W
         stream = _stream()
         f32 = dict(dtype=torch.float32, device=dev)
+        needs = ctx.needs_input_grad
+        if ctx.pooled and dpl is not None:
+            # the block's output fed the pool AND the skip connection: one pass adds the two gradients (PoolSkip's job)
+            dpl = _as_nhwc(dpl)
+            dsum = torch.empty((N, H, W, ldy), dtype=y.dtype, device=dev)
+            if da is None:
+                call("mau_maxpool2x2_bwd", a.data_ptr(), ldy, dpl.data_ptr(), _ld(dpl), dsum.data_ptr(), ldy, code, N, H, W, Cout, stream)
+            else:
+                da = _as_nhwc(da)
+                call("mau_maxpool2x2_bwd_add", a.data_ptr(), ldy, dpl.data_ptr(), _ld(dpl), da.data_ptr(), _ld(da),
+                     dsum.data_ptr(), ldy, code, N, H, W, Cout, stream)
+            da = dsum
+        elif da is None:
+            da = torch.zeros((N, H, W, ldy), dtype=y.dtype, device=dev)
+        da = _as_nhwc(da)
         # --- BN + ReLU backward: two passes over (da, y) ---
         rows = lib.mau_bn_bwd_rows(npix)
         slab = torch.empty((rows, 2 * Cout), **f32)
         call("mau_bn_relu_bwd_reduce", da.data_ptr(), _ld(da), y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(),
              mean.data_ptr(), invstd.data_ptr(), slab.data_ptr(), Cout, code, npix, Cout, stream)
-        sums = torch.empty(2 * Cout, dtype=torch.float64, device=dev)
+        sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
         ws = torch.empty(lib.mau_reduce_rows_ws_elems(rows, 2 * Cout), dtype=torch.float64, device=dev)
         g32 = torch.empty(2 * Cout, **f32)                   # [dbeta | dgamma]: the LOCAL sums, rounded to fp32 by the reducer
         call("mau_reduce_rows_f64_f32", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), g32.data_ptr(), ws.data_ptr(), stream)
         dgamma = g32[Cout:]
         dbeta = g32[:Cout]
         if st.training:
-            _all_reduce_(sums, st)
-            sums_apply, count = sums, float(npix * st.world)
+            if st.group is not None:
+                sums[2 * Cout] = float(npix)                 # the global count travels with the sums (see forward)
+                _all_reduce_(sums, st)
+                sums_apply, count = sums, 0.0
+            else:
+                sums_apply, count = sums, float(npix)
         else:
             sums_apply, count = torch.zeros_like(sums), float(npix)     # eval-mode BN is a fixed affine map
         dy = torch.empty_like(y)
         call("mau_bn_relu_bwd_apply", da.data_ptr(), _ld(da), y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(),
              mean.data_ptr(), invstd.data_ptr(), sums_apply.data_ptr(), count, dy.data_ptr(), ldy, code, npix, Cout, stream)
-        # --- weight gradient: independent of the data gradient given dy -> runs on a side stream so the two
-        #     kernels (often only 256-512 workgroups each) fill each other's tails; joined before returning ---
+        # --- weight gradient: independent of the data gradient given dy ---
         dw = None
-        need_dx = ctx.needs_input_grad[0] or (E and ctx.needs_input_grad[1])
-        side = _side_stream(dev) if (ctx.needs_input_grad[2] and need_dx and _OVERLAP_WGRAD) else None
-        if ctx.needs_input_grad[2]:
+        need_dx = needs[0] or (x1 is not None and needs[1]) or (E and needs[2])
+        side = _side_stream(dev) if (needs[3] and need_dx and _OVERLAP_WGRAD) else None
+        if needs[3]:
             acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), **f32)
             emb_ws = torch.empty((N, E), dtype=y.dtype, device=dev) if E else None
             dw = torch.empty_like(weight)
@@ -308,32 +385,43 @@ class ConvBNReLU(torch.autograd.Function):
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream())
                 wstream = side.cuda_stream
-            call("mau_conv3x3_wgrad", x.data_ptr(), _ld(x), st.C0, emb.data_ptr() if E else None,
+            call("mau_conv3x3_wgrad2", x.data_ptr(), _ld(x), st.C0, x1.data_ptr() if x1 is not None else None,
+                 _ld(x1) if x1 is not None else 0, C1, emb.data_ptr() if E else None,
                  emb_ws.data_ptr() if E else None, E, dy.data_ptr(), ldy, Cout, acc.data_ptr(), code, N, H, W, wstream)
             call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin),
                  dw.data_ptr(), Cout, Cin, wstream)
         # --- data gradient (same implicit-GEMM kernel, rotated/transposed weight pack) ---
-        dx = demb = None
+        dx = dx1 = demb = None
         if need_dx:
             wd = ctx.wd if ctx.wd is not None else pack_conv_weights(weight, code, forward=False, dgrad=True)[1]
             ldd = pad8(Cin)
             dfull = torch.empty((N, H, W, ldd), dtype=y.dtype, device=dev)
             call("mau_conv3x3_fwd", dy.data_ptr(), ldy, Cout, None, None, 0, wd.data_ptr(), None, None, None, dfull.data_ptr(),
                  ldd, Cin, None, code, N, H, W, stream)
-            if E:
-                if ctx.needs_input_grad[1]:
-                    demb = torch.empty((N, E), **f32)
-                    ws = torch.empty(lib.mau_bcast_bwd_ws_elems(N, H * W, E), **f32)
-                    call("mau_bcast_bwd", dfull.data_ptr(), ldd, st.C0, demb.data_ptr(), ws.data_ptr(), code, N, H * W, E, stream)
-                if ctx.needs_input_grad[0]:
-                    dx = dfull[..., :pad8(st.C0)]            # C0 % 8 == 0 is enforced by the kernel when E > 0
-            else:
-                dx = dfull
+            Ct = st.C0 + C1
+            if E and needs[2]:
+                demb = torch.empty((N, E), **f32)
+                ws = torch.empty(lib.mau_bcast_bwd_ws_elems(N, H * W, E), **f32)
+                call("mau_bcast_bwd", dfull.data_ptr(), ldd, Ct, demb.data_ptr(), ws.data_ptr(), code, N, H * W, E, stream)
+            if C1:
+                # the two tensors' gradients are channel slices of one buffer (C0 % 16 == 0; with E > 0 also C1 % 8 == 0)
+                if needs[0]:
+                    dx = dfull[..., :st.C0]
+                if needs[1]:
+                    dx1 = dfull[..., st.C0:st.C0 + pad8(C1)]
+            elif needs[0]:
+                dx = dfull[..., :pad8(st.C0)] if E else dfull           # C0 % 8 == 0 is enforced by the kernel when E > 0
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-        # conv bias followed by train-mode BN has an identically zero gradient (the batch mean absorbs it)
-        dbias = torch.zeros(Cout, **f32) if ctx.needs_input_grad[3] else None
-        return dx, demb, dw, dbias, dgamma, dbeta, None, None, None, None
+        dbias = None
+        if needs[4]:
+            if st.training:
+                # conv bias followed by train-mode BN has an identically zero gradient (the batch mean absorbs it)
+                dbias = torch.zeros(Cout, **f32)
+            else:
+                # eval-mode BN is the fixed affine map z = scale*y + shift: d/dbias = sum(dy) = scale * sum(dz)
+                dbias = scale * dbeta
+        return dx, dx1, demb, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
 # --------------------------------------------------------------------------- #
@@ -408,6 +496,47 @@ def _resize_into(src, Cs, h, w, dst, choff, N, H, W, code, stream):
         tmp = torch.empty((N, H, W, pad8(Cs)), dtype=dst.dtype, device=dst.device)
         call("mau_resize_bilinear_fwd", src.data_ptr(), _ld(src), h, w, tmp.data_ptr(), pad8(Cs), 0, code, N, H, W, Cs, stream)
         call("mau_copy_channels", tmp.data_ptr(), pad8(Cs), dst.data_ptr(), _ld(dst), choff, 0, code, N * H * W, Cs, stream)
+
+
+class UpsampleTo(torch.autograd.Function):
+    """_upsample_match(up(low), skip) as a tensor of its own: the decoder convolution then reads [skip, up] as two loader
+    sources (virtual concat).  ``two_step=True`` = the U-Net's x2 upsample followed by a second resize only if the sizes
+    differ (src/model.py:219,243-246); ``False`` = U-Net++'s direct resize to the target (src/model.py:111-121)."""
+
+    @staticmethod
+    def forward(ctx, low, C_low, two_step, H, W):
+        low = _as_nhwc(low)
+        N, h, w, _ = low.shape
+        code = dtype_code(low.dtype)
+        stream = _stream()
+        ld = pad8(C_low)
+        src, sh, sw = low, h, w
+        mid = None
+        if two_step and (2 * h, 2 * w) != (H, W):
+            mid = torch.empty((N, 2 * h, 2 * w, ld), dtype=low.dtype, device=low.device)
+            call("mau_resize_bilinear_fwd", low.data_ptr(), _ld(low), h, w, mid.data_ptr(), ld, 0, code, N, 2 * h, 2 * w, C_low, stream)
+            src, sh, sw = mid, 2 * h, 2 * w
+        out = torch.empty((N, H, W, ld), dtype=low.dtype, device=low.device)
+        call("mau_resize_bilinear_fwd", src.data_ptr(), _ld(src), sh, sw, out.data_ptr(), ld, 0, code, N, H, W, C_low, stream)
+        ctx.meta = (C_low, (h, w), (H, W), mid is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        C_low, (h, w), (H, W), two = ctx.meta
+        g = _as_nhwc(g)
+        N = g.shape[0]
+        code = dtype_code(g.dtype)
+        stream = _stream()
+        ld = pad8(C_low)
+        gsrc, gld, sH, sW = g, _ld(g), H, W
+        if two:
+            dmid = torch.empty((N, 2 * h, 2 * w, ld), dtype=g.dtype, device=g.device)
+            call("mau_resize_bilinear_bwd", g.data_ptr(), gld, 0, H, W, dmid.data_ptr(), ld, code, N, 2 * h, 2 * w, C_low, stream)
+            gsrc, gld, sH, sW = dmid, ld, 2 * h, 2 * w
+        dlow = torch.empty((N, h, w, ld), dtype=g.dtype, device=g.device)
+        call("mau_resize_bilinear_bwd", gsrc.data_ptr(), gld, 0, sH, sW, dlow.data_ptr(), ld, code, N, h, w, C_low, stream)
+        return dlow, None, None, None, None
 
 
 class ConcatUp(torch.autograd.Function):

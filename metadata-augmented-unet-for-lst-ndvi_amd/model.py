@@ -16,8 +16,9 @@ same ``torch.manual_seed`` gives the same initial weights); their ``forward`` is
 the hot path -- all arithmetic runs in the HIP kernels behind ``functional``.
 
 Extras that the reference does not have (all optional, defaults keep reference behaviour):
-  * ``model.set_precision("bf16" | "fp32")`` -- throughput mode vs fp32 parity mode
-    (default from env ``MAU_PRECISION``, else "bf16");
+  * ``model.set_precision("bf16" | "fp16" | "fp32")`` -- bf16 throughput mode (default; env ``MAU_PRECISION``),
+    the same kernels on fp16 operands (``v_mfma_f32_32x32x16_f16``, fp32 accumulation; inference, BASELINE
+    configs[4]), or the fp32 parity mode;
   * ``model.set_sync_bn(process_group)``     -- BatchNorm statistics all-reduced over RCCL.
 """
 from __future__ import annotations
@@ -31,7 +32,7 @@ import torch.nn as nn
 from . import functional as F_
 from .functional import Act, BNState
 
-_DTYPES = {"bf16": torch.bfloat16, "fp32": torch.float32}
+_DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 
 def _default_precision() -> str:
@@ -67,18 +68,23 @@ class VGGBlock(nn.Module):
         self._rt: Optional[_Runtime] = None
         self._frozen = None               # [dict, dict] while a frozen inference session is active
 
-    def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d) -> Act:
+    def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d, x1: Optional[Act] = None, pool: bool = False):
         rt = self._rt or _Runtime()
         st = BNState(training=self.training and bn.training, C0=x.C, momentum=bn.momentum, eps=bn.eps,
                      group=rt.group, world=rt.world, grad_enabled=torch.is_grad_enabled(),
-                     frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1])
-        t = F_.ConvBNReLU.apply(x.t, emb, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                                bn.running_var, bn.num_batches_tracked, st)
+                     frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1],
+                     C1=0 if x1 is None else x1.C, pool=pool)
+        t = F_.ConvBNReLU.apply(x.t, None if x1 is None else x1.t, emb, conv.weight, conv.bias, bn.weight, bn.bias,
+                                bn.running_mean, bn.running_var, bn.num_batches_tracked, st)
+        if pool:
+            return Act(t[0], conv.out_channels), Act(t[1], conv.out_channels)
         return Act(t, conv.out_channels)
 
-    def forward(self, x: Act, emb: Optional[torch.Tensor] = None) -> Act:
-        x = self._half(x, emb, self.conv1, self.bn1)
-        return self._half(x, None, self.conv2, self.bn2)
+    def forward(self, x: Act, emb: Optional[torch.Tensor] = None, x1: Optional[Act] = None, pool: bool = False):
+        """``x1``: second input tensor, channel-concatenated after ``x`` by the conv loader (never materialised);
+        ``pool=True`` returns ``(block output, maxpool2x2(block output))``."""
+        x = self._half(x, emb, self.conv1, self.bn1, x1)
+        return self._half(x, None, self.conv2, self.bn2, None, pool)
 
 
 class TemporalEncoder(nn.Module):
@@ -162,12 +168,15 @@ class _NetBase(nn.Module):
             return maps
         return Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
 
-    def _pool_skip(self, a: Act):
-        """(pool(a), a) for an encoder activation that also feeds a skip connection: one fused backward pass."""
-        if not (torch.is_grad_enabled() and a.t.requires_grad):
-            return self._pool(a), a
-        y, skip = F_.PoolSkip.apply(a.t, a.C)
-        return Act(y, a.C), Act(skip, a.C)
+    def _block_pool(self, block: VGGBlock, x: Act):
+        """(pool(block(x)), block(x)): the encoder block's second BatchNorm+ReLU pass also writes the pooled tensor, and
+        its backward adds the pool's and the skip connection's gradients in one pass."""
+        a, p = block(x, pool=True)
+        return p, a
+
+    def _fusable(self, skip: Act) -> bool:
+        """Virtual concat needs a 16-bit activation dtype and a first tensor that ends on a 16-channel stage boundary."""
+        return self._rt.dtype != torch.float32 and skip.C % 16 == 0 and os.environ.get("MAU_VIRTUAL_CONCAT", "1") != "0"
 
     def _pool(self, a: Act) -> Act:
         return Act(F_.MaxPool2x2.apply(a.t, a.C), a.C)
@@ -209,10 +218,13 @@ class UrbanPredictor_unet(_NetBase):
         self.final = nn.Conv2d(nb_filter[0], out_channels, kernel_size=1)
         self._bind_runtime()
 
-    def _up_cat(self, skip: Act, low: Act) -> Act:
-        # cat([skip, _upsample_match(up(low), skip)], 1), src/model.py:243-246,279-282
+    def _dec(self, block: VGGBlock, skip: Act, low: Act) -> Act:
+        # block(cat([skip, _upsample_match(up(low), skip)], 1)), src/model.py:243-246,279-282
+        if self._fusable(skip):
+            up = Act(F_.UpsampleTo.apply(low.t, low.C, True, skip.H, skip.W), low.C)
+            return block(skip, None, up)                 # [skip, up] are two sources of the conv loader: no concat buffer
         t = F_.ConcatUp.apply(low.t, low.C, True, (skip.C,), skip.t)
-        return Act(t, skip.C + low.C)
+        return block(Act(t, skip.C + low.C))
 
     def _fused_block(self, block: VGGBlock, x: Act, embs: List[torch.Tensor]) -> Act:
         """conv4_0(fuse_embeddings(x, ...)) with the broadcast folded into the conv loader (src/model.py:248-259)."""
@@ -228,15 +240,15 @@ class UrbanPredictor_unet(_NetBase):
         temporal_emb = self.temporal_encoder(temp_series) if self.temporal_embeddings else None
         meta_emb = self.meta_encoder(metadata) if self.metadata_embeddings else None
         x = self._entry(maps)
-        p, x0_0 = self._pool_skip(self.conv0_0(x))
-        p, x1_0 = self._pool_skip(self.conv1_0(p))
-        p, x2_0 = self._pool_skip(self.conv2_0(p))
-        x4_0, x3_0 = self._pool_skip(self.conv3_0(p))
+        p, x0_0 = self._block_pool(self.conv0_0, x)
+        p, x1_0 = self._block_pool(self.conv1_0, p)
+        p, x2_0 = self._block_pool(self.conv2_0, p)
+        x4_0, x3_0 = self._block_pool(self.conv3_0, p)
         x4_0 = self._fused_block(self.conv4_0, x4_0, [e for e in (temporal_emb, meta_emb) if e is not None])
-        x3_1 = self.conv3_1(self._up_cat(x3_0, x4_0))
-        x2_1 = self.conv2_1(self._up_cat(x2_0, x3_1))
-        x1_1 = self.conv1_1(self._up_cat(x1_0, x2_1))
-        x0_1 = self.conv0_1(self._up_cat(x0_0, x1_1))
+        x3_1 = self._dec(self.conv3_1, x3_0, x4_0)
+        x2_1 = self._dec(self.conv2_1, x2_0, x3_1)
+        x1_1 = self._dec(self.conv1_1, x1_0, x2_1)
+        x0_1 = self._dec(self.conv0_1, x0_0, x1_1)
         return self._head(x0_1)
 
 
@@ -269,10 +281,10 @@ class UrbanPredictor_unet(_NetBase):
 
         x0_0, x1_0, x2_0, x3_0, x4_0 = rep(x0_0), rep(x1_0), rep(x2_0), rep(x3_0), rep(x4_0)
         x4_0 = self._fused_block(self.conv4_0, x4_0, [e for e in (temporal_emb, meta_emb) if e is not None])
-        x3_1 = self.conv3_1(self._up_cat(x3_0, x4_0))
-        x2_1 = self.conv2_1(self._up_cat(x2_0, x3_1))
-        x1_1 = self.conv1_1(self._up_cat(x1_0, x2_1))
-        x0_1 = self.conv0_1(self._up_cat(x0_0, x1_1))
+        x3_1 = self._dec(self.conv3_1, x3_0, x4_0)
+        x2_1 = self._dec(self.conv2_1, x2_0, x3_1)
+        x1_1 = self._dec(self.conv1_1, x1_0, x2_1)
+        x0_1 = self._dec(self.conv0_1, x0_0, x1_1)
         return self._head(x0_1)
 
 
@@ -315,6 +327,10 @@ class UrbanPredictor_unetpp(_NetBase):
 
     def _node(self, block: VGGBlock, skips: List[Act], below: Act, emb: torch.Tensor) -> Act:
         # cat([skips..., _upsample_match(below, (H, W)), emb_map], 1), src/model.py:111-121,136-177
+        fused_emb = (sum(s.C for s in skips) + below.C) % 8 == 0 and emb.shape[1] % 8 == 0
+        if len(skips) == 1 and fused_emb and self._fusable(skips[0]):
+            up = Act(F_.UpsampleTo.apply(below.t, below.C, False, skips[0].H, skips[0].W), below.C)
+            return block(skips[0], emb, up)           # [skip, up, broadcast(emb)]: three sources of the conv loader
         t = F_.ConcatUp.apply(below.t, below.C, False, tuple(s.C for s in skips), *[s.t for s in skips])
         x = Act(t, sum(s.C for s in skips) + below.C)
         if x.C % 8 == 0 and emb.shape[1] % 8 == 0:
@@ -326,13 +342,13 @@ class UrbanPredictor_unetpp(_NetBase):
         meta_emb = self.meta_encoder(metadata)
         emb = torch.cat([temporal_emb, meta_emb], dim=1).float()           # src/model.py:103
         x = self._entry(maps)
-        p, x0_0 = self._pool_skip(self.conv0_0(x))          # (the skip copy feeds every node of the row)
-        p, x1_0 = self._pool_skip(self.conv1_0(p))
+        p, x0_0 = self._block_pool(self.conv0_0, x)         # (the skip feeds every node of the row)
+        p, x1_0 = self._block_pool(self.conv1_0, p)
         x0_1 = self._node(self.conv0_1, [x0_0], x1_0, emb)
-        p, x2_0 = self._pool_skip(self.conv2_0(p))
+        p, x2_0 = self._block_pool(self.conv2_0, p)
         x1_1 = self._node(self.conv1_1, [x1_0], x2_0, emb)
         x0_2 = self._node(self.conv0_2, [x0_0, x0_1], x1_1, emb)
-        p, x3_0 = self._pool_skip(self.conv3_0(p))
+        p, x3_0 = self._block_pool(self.conv3_0, p)
         x2_1 = self._node(self.conv2_1, [x2_0], x3_0, emb)
         x1_2 = self._node(self.conv1_2, [x1_0, x1_1], x2_1, emb)
         x0_3 = self._node(self.conv0_3, [x0_0, x0_1, x0_2], x1_2, emb)

@@ -126,3 +126,24 @@ def test_rccl_collectives_one_rank_group(tmp_path):
         for k in a:
             err = float((a[k] - b[k]).abs().max())
             assert err < tol * float(a[k].abs().max()) or err < 1e-6, (prec, k, err)
+
+
+def test_bench_self_launches_two_ranks(tmp_path):
+    """``python bench.py --gpus 2`` outside torch.distributed.run must start its own two ranks (child processes; the
+    parent never touches the GPU), and print ONE JSON line with n_gpus 2; N = 1 keeps printing its line directly.
+    Two ranks share cuda:0 here, so the collectives run over gloo (MAU_DIST_BACKEND) -- rccl_ranks is then 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MAU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "2", "--warmup", "1", "--batch", "2", "--size", "64", "--no-cpu-baseline"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["steps"] == 2 and rec["rccl_ranks"] == 0
+    assert rec["config"]["sync_bn"] is True and rec["value"] > 0 and rec["roofline"]["achieved"] > 0
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    rec1 = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec1["n_gpus"] == 1 and rec1["rccl_ranks"] == 1 and "cpu_baseline" not in rec1

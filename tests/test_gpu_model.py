@@ -70,7 +70,6 @@ def test_fp32_parity_full_model(mau, name):
             assert float((a - v).abs().max()) <= 2.5 * m["lr"], k
 
 
-@pytest.mark.parametrize("name", FULL)
 def _autocast_yardstick(d, m):
     """Error of the REFERENCE algorithm itself under torch's CPU bf16 autocast vs its fp32 result:
     the inherent bf16 noise of this network/fixture (ReLU-mask flips, tiny-batch BatchNorm)."""
@@ -147,12 +146,12 @@ def test_production_shape_fp32_vs_oracle(mau, model_type, B):
     (250->125->62->31->15: every decoder level takes the odd-size second resize), 8 metadata features,
     temporal + metadata embeddings, base_filters 64.  HIP fp32 path vs the CPU oracle, same seed.
 
-    Tolerances: outputs and loss <= 1e-3 (north star).  Gradients at this depth/batch are judged at 1.5e-2 relative L2 and 1.6e-1 max-norm (2x the yardstick):
-    the reference's OWN fp32 gradients differ from an fp64 evaluation of the same graph by up to 8.1e-2
-    max-norm / 7.1e-3 relative L2 (U-Net B=2: conv3_0.conv1.weight; U-Net++ B=1: 5.2e-2), measured with
-    the oracle in the build container: ReLU masks flip where a pre-activation differs in the last bits
-    and small-batch BatchNorm amplifies it.  The HIP fp32 path shows the same figures on the same
-    parameters (8.2e-2 / 7.3e-3), i.e. it is as close to the reference as the reference is to exact math."""
+    Tolerances: outputs and loss <= 1e-3 max-norm (north star).  Gradients at this depth/batch are judged against a
+    yardstick COMPUTED HERE: the deviation of the reference's own fp32 gradients from an fp64 evaluation of the same
+    graph on the same inputs (ReLU masks flip where a pre-activation differs in the last bits and small-batch BatchNorm
+    amplifies it).  Bound: 2x that deviation (+1e-3) -- relative L2 per parameter, max-norm against the worst parameter's
+    deviation -- i.e. the HIP fp32 path must be as close to the reference as the reference is to exact arithmetic.  The element-wise
+    ``allclose(rtol=1e-3, atol=1e-3*max|ref|)`` pass fraction is printed next to the max-norm figure."""
     flags = {} if model_type == "unet++" else dict(temporal_embeddings=True, metadata_embeddings=True)
     torch.manual_seed(11)
     net = mau.UrbanPredictor(model_type, 23, 12, 64, 8, 64, 96, 2, base_filters=64, **flags)
@@ -166,6 +165,11 @@ def test_production_shape_fp32_vs_oracle(mau, model_type, B):
     ref = R.forward(model_type, sd, x, ts, md, True, **flags)
     ref_loss = R.loss_mse(ref, tgt)["total"]
     ref_loss.backward()
+    # yardstick: the same graph in fp64 (same oracle code, double tensors)
+    sd64 = {k: (v.detach().double().requires_grad_(True) if R.is_param(k) else v.detach().clone().double() if v.is_floating_point() else v.clone())
+            for k, v in sd0.items()}
+    ref64 = R.forward(model_type, sd64, x.double(), ts.double(), md.double(), True, **flags)
+    R.loss_mse(ref64, tgt.double())["total"].backward()
     net = net.cuda().set_precision("fp32").train()
     out = net(x.cuda(), ts.cuda(), md.cuda())
     loss = mau.compute_loss_mse(out, tgt.cuda())["total"]
@@ -173,13 +177,26 @@ def test_production_shape_fp32_vs_oracle(mau, model_type, B):
     assert rel_err(out.detach().cpu(), ref.detach()) < 1e-3
     assert abs(float(loss) - float(ref_loss)) < 1e-4 * float(ref_loss)
     params = dict(net.named_parameters())
-    for k, v in sd.items():
-        if not R.is_param(k) or v.grad is None or k.endswith(".conv1.bias") or k.endswith(".conv2.bias"):
-            continue
+    worst = (0.0, 0.0, 0.0, 0.0, "")
+    close_n = close_d = 0
+    keys = [k for k, v in sd.items() if R.is_param(k) and v.grad is not None and not k.endswith((".conv1.bias", ".conv2.bias"))]
+    # max-norm is decided by single ReLU-mask flips and jumps from parameter to parameter: its yardstick is the reference's
+    # WORST fp32-vs-fp64 max-norm deviation over all parameters; relative L2 is judged per parameter
+    y_max = max(rel_err(sd[k].grad, sd64[k].grad) for k in keys)
+    for k in keys:
+        v = sd[k]
         got = params[k].grad.cpu()
         e, e2 = rel_err(got, v.grad), rel_l2(got, v.grad)
+        y_e, y_e2 = rel_err(v.grad, sd64[k].grad), rel_l2(v.grad, sd64[k].grad)      # reference fp32 vs fp64
         small = float((got - v.grad).abs().max()) < 1e-6
-        assert (e < 1.6e-1 and e2 < 1.5e-2) or small, (k, e, e2)   # 2x the reference's own fp32-vs-fp64 deviation
+        assert (e <= 2 * y_max + 1e-3 and e2 <= 2 * y_e2 + 1e-3) or small, (k, e, e2, y_max, y_e2)
+        if e > worst[0]:
+            worst = (e, e2, y_e, y_e2, k)
+        close_n += int(torch.isclose(got, v.grad, rtol=1e-3, atol=1e-3 * float(v.grad.abs().max())).sum())
+        close_d += got.numel()
+    print(f"{model_type}: worst gradient max-norm {worst[0]:.2e} / relL2 {worst[1]:.2e} on {worst[4]} "
+          f"(reference fp32-vs-fp64 there: {worst[2]:.2e} / {worst[3]:.2e}); element-wise allclose(1e-3) pass fraction "
+          f"{close_n / max(close_d, 1):.6f}")
     # bf16 throughput mode on the same shape: finite, and close in relative L2
     net.zero_grad(set_to_none=True)
     net.load_state_dict(sd0)
@@ -285,6 +302,143 @@ def test_frozen_inference_matches_and_unfreezes(mau):
     assert blk._frozen is None
     net.eval().freeze_inference().set_precision("fp32")
     assert blk._frozen is None
+
+
+@pytest.mark.parametrize("model_type", ["unet", "unet++"])
+def test_virtual_concat_and_fused_pool_are_bitwise_equal_to_materialised(mau, model_type, monkeypatch):
+    """The decoder's torch.cat([skip, up], 1) (src/model.py:279-282) read by the conv loader from two tensors must give,
+    bit for bit, the results of the materialised concat buffer (same K order, same arithmetic): outputs, loss and every
+    gradient of one bf16 training step at base_filters=16 (all channel counts on 16-channel stage boundaries)."""
+    flags = {} if model_type == "unet++" else dict(temporal_embeddings=False, metadata_embeddings=True)
+    g = torch.Generator().manual_seed(31)
+    x, ts, md = torch.randn(2, 6, 48, 40, generator=g).cuda(), torch.randn(2, 10, generator=g).cuda(), torch.randn(2, 4, generator=g).cuda()
+    tgt = torch.randn(2, 2, 48, 40, generator=g).cuda()
+    res = []
+    for virt in ("1", "0"):
+        monkeypatch.setenv("MAU_VIRTUAL_CONCAT", virt)
+        torch.manual_seed(30)
+        net = mau.UrbanPredictor(model_type, 6, 10, 16, 4, 16, 24, 2, base_filters=16, **flags).cuda().set_precision("bf16").train()
+        out = net(x, ts, md)
+        loss = mau.compute_loss_mse(out, tgt)["total"]
+        loss.backward()
+        res.append((out.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][2].keys() == res[1][2].keys()
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_training_step_is_bitwise_reproducible(mau, prec):
+    """Two identical steps from identical state give bit-identical outputs, loss, gradients and BatchNorm buffers: every
+    reduction of the path (BatchNorm statistics, split-K weight gradient, loss, head) is slab + fixed-order, no atomics."""
+    g = torch.Generator().manual_seed(41)
+    x, ts, md = torch.randn(4, 6, 64, 64, generator=g).cuda(), torch.randn(4, 10, generator=g).cuda(), torch.randn(4, 4, generator=g).cuda()
+    tgt = torch.randn(4, 2, 64, 64, generator=g).cuda()
+    res = []
+    for _ in range(2):
+        torch.manual_seed(40)
+        net = mau.UrbanPredictor("unet", 6, 10, 16, 4, 16, 24, 2, base_filters=32, temporal_embeddings=False).cuda().set_precision(prec).train()
+        out = net(x, ts, md)
+        loss = mau.compute_loss_mse(out, tgt)["total"]
+        loss.backward()
+        res.append((out.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    for k in res[0][3]:
+        assert torch.equal(res[0][3][k], res[1][3][k]), k
+
+
+@pytest.mark.parametrize("name", ["g5_unet_even.npz", "g5_unet_odd.npz", "g6_unetpp.npz"])
+def test_fp16_mode_full_model(mau, name):
+    """fp16 mode (v_mfma_f32_32x32x16_f16, fp32 accumulation; BASELINE configs[4]): eval and train outputs against the
+    reference fixtures.  fp16 carries 3 more mantissa bits than bf16, so it is held to the bf16 yardstick without slack
+    factor; the training gradients (no loss scaling) are checked in relative L2 against the same yardstick."""
+    d = load_npz(name)
+    net, m = build(mau, d, "fp16")
+    out_yard, grad_yard = _autocast_yardstick(d, m)
+    x, ts, md, tgt = (t(d[k]).cuda() for k in ("x", "ts", "md", "tgt"))
+    net.eval()
+    with torch.no_grad():
+        e_eval = rel_l2(net(x, ts, md).cpu(), t(d["out_eval"]))
+    net.train()
+    out = net(x, ts, md)
+    e_out = rel_l2(out.detach().cpu(), t(d["out_train"]))
+    loss = mau.compute_loss_mse(out, tgt)["total"]
+    loss.backward()
+    params = dict(net.named_parameters())
+    gref = sub(d, "grad")
+    num = sum(float(((params[k].grad.cpu().double() - g.double()) ** 2).sum()) for k, g in gref.items())
+    den = sum(float((g.double() ** 2).sum()) for g in gref.values())
+    e_grad = (num / den) ** 0.5
+    print(f"{name}: fp16 eval relL2 {e_eval:.4f}, train relL2 {e_out:.4f} (bf16 autocast yardstick {out_yard:.4f}); grad relL2 {e_grad:.4f} ({grad_yard:.4f})")
+    assert e_eval <= 5e-3
+    assert e_out <= out_yard + 5e-3
+    assert e_grad <= grad_yard + 2e-2
+
+
+CONFIG5 = [(6, 4, dict(temporal_embeddings=False, metadata_embeddings=True)), (23, 8, dict(temporal_embeddings=True, metadata_embeddings=True))]
+
+
+@pytest.mark.parametrize("cin,nmeta,flags", CONFIG5, ids=["6ch-4meta", "23ch-8meta-app"])
+def test_config5_512x512_inference_vs_oracle(mau, cin, nmeta, flags):
+    """BASELINE configs[4] / the Streamlit app's call (app/model_utils.py:102-109, app/processing_utils.py:112-177): base-64
+    U-Net, eval mode, ONE 512x512 tile, against the CPU oracle on the same seeded weights and inputs.  BatchNorm running
+    statistics are first moved off their initial (0, 1) by two training-mode forwards of the oracle, so that the folded
+    BN+ReLU epilogue is exercised with non-trivial coefficients.
+      fp32 parity mode <= 1e-3 max-norm;  bf16 / fp16 by relative L2 (<= 3e-2 / <= 5e-3);
+    through the plain eval forward, ``freeze_inference()`` and ``GraphedInference`` (which must agree bit for bit)."""
+    torch.manual_seed(50 + cin)
+    net = mau.UrbanPredictor("unet", cin, 12, 64, nmeta, 64, 96, 2, base_filters=64, **flags)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(51)
+    with torch.no_grad():
+        for _ in range(2):      # running statistics: two train-mode passes of the oracle at 64x64 (updates sd's buffers in place)
+            R.forward("unet", sd, torch.randn(4, cin, 64, 64, generator=g), torch.randn(4, 12, generator=g), torch.randn(4, nmeta, generator=g), True, **flags)
+    x, ts, md = torch.randn(1, cin, 512, 512, generator=g), torch.randn(1, 12, generator=g), torch.randn(1, nmeta, generator=g)
+    with torch.no_grad():
+        ref = R.forward("unet", sd, x, ts, md, False, **flags)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    xc, tc, mc = x.cuda(), ts.cuda(), md.cuda()
+    for prec, metric, tol in (("fp32", rel_err, 1e-3), ("bf16", rel_l2, 3e-2), ("fp16", rel_l2, 5e-3)):
+        net.set_precision(prec)
+        with torch.no_grad():
+            plain = net(xc, tc, mc)
+            net.freeze_inference()
+            frozen = net(xc, tc, mc)
+            sess = mau.GraphedInference(net, xc, tc, mc)
+            graphed = sess(xc, tc, mc)
+            net.freeze_inference(False)
+        e = metric(plain.cpu(), ref)
+        print(f"config5 {cin}ch {prec}: {metric.__name__} {e:.2e}")
+        assert plain.shape == (1, 2, 512, 512) and e <= tol, (prec, e)
+        assert torch.equal(plain, frozen) and torch.equal(plain, graphed), prec
+
+
+def test_metadata_sweep_vs_oracle_250(mau):
+    """forward_metadata_sweep at the reference's production tile (250x250x23, 8 metadata features; the sensitivity sweeps
+    of test/metadata_sensitivity.py:294-311 repeat one tile B times) against the ORACLE's repeated-tile eval forward."""
+    flags = dict(temporal_embeddings=False, metadata_embeddings=True)
+    torch.manual_seed(60)
+    net = mau.UrbanPredictor("unet", 23, 12, 32, 8, 32, 24, 2, base_filters=16, **flags)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(61)
+    with torch.no_grad():
+        R.forward("unet", sd, torch.randn(4, 23, 62, 62, generator=g), torch.randn(4, 12, generator=g), torch.randn(4, 8, generator=g), True, **flags)
+    B = 5
+    x, ts, md = torch.randn(1, 23, 250, 250, generator=g), torch.randn(1, 12, generator=g), torch.randn(B, 8, generator=g)
+    with torch.no_grad():
+        ref = R.forward("unet", sd, x.expand(B, -1, -1, -1), ts.expand(B, -1), md, False, **flags)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    for prec, metric, tol in (("fp32", rel_err, 1e-3), ("bf16", rel_l2, 3e-2)):
+        net.set_precision(prec)
+        got = net.forward_metadata_sweep(x.cuda(), ts.cuda(), md.cuda())
+        assert got.shape == (B, 2, 250, 250)
+        assert metric(got.cpu(), ref) <= tol, prec
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])

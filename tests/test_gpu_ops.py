@@ -60,7 +60,7 @@ def _exact_int_case(g, N, Cin, Cout, H, W):
     return x, w, b
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (1, 8, 64, 31, 17),
                                    (1, 3, 5, 2, 3), (4, 8, 8, 3, 3), (2, 17, 70, 5, 40), (1, 64, 64, 16, 16), (9, 1, 1, 1, 1),
                                    (3, 200, 72, 20, 34),
@@ -87,10 +87,10 @@ def test_conv3x3_exact_integers(mau, dt, shape):
     call("mau_conv3x3_fwd", a.t.data_ptr(), a.t.shape[-1], Cin, None, None, 0, wf.data_ptr(), dev(b).data_ptr(), None, None, y.data_ptr(),
          y.shape[-1], Cout, slab.data_ptr(), code, N, H, W, torch.cuda.current_stream().cuda_stream)
     got = from_act(mau, F_.Act(y, Cout))
-    if dt == torch.float32 or float(ref.abs().max()) < 256:
+    if dt == torch.float32 or float(ref.abs().max()) < (256 if dt == torch.bfloat16 else 2048):
         assert torch.equal(got, ref)
-    else:       # outputs beyond bf16's exact integer range are rounded once on store
-        assert torch.equal(got, ref.bfloat16().float())
+    else:       # outputs beyond the 16-bit type's exact integer range are rounded once on store
+        assert torch.equal(got, ref.to(dt).float())
     assert float(y[..., Cout:].float().abs().sum()) == 0.0
     # fused BatchNorm partial statistics (fp32 accumulators, before the output rounding)
     s = slab.double().sum(0).cpu()
@@ -101,7 +101,7 @@ def test_conv3x3_exact_integers(mau, dt, shape):
         assert torch.allclose(s[:Cout], s1, rtol=1e-6, atol=1.0) and torch.allclose(s[cpad:cpad + Cout], s2, rtol=1e-6)
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (3, 64, 128, 24, 40),
                                    (2, 136, 256, 16, 16), (1, 3, 5, 2, 3), (4, 8, 8, 3, 3), (9, 1, 1, 1, 1), (2, 17, 70, 5, 40),
                                    (6, 24, 130, 70, 100), (8, 64, 256, 96, 112), (3, 40, 128, 33, 17)])
@@ -123,7 +123,7 @@ def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
     call("mau_conv3x3_fwd", dya.t.data_ptr(), dya.t.shape[-1], Cout, None, None, 0, wdp.data_ptr(), None, None, None, dx.data_ptr(),
          dx.shape[-1], Cin, None, code, N, H, W, st)
     got_dx = from_act(mau, F_.Act(dx, Cin))
-    ref_dx = x.grad if (dt == torch.float32 or float(x.grad.abs().max()) < 256) else x.grad.bfloat16().float()
+    ref_dx = x.grad if (dt == torch.float32 or float(x.grad.abs().max()) < (256 if dt == torch.bfloat16 else 2048)) else x.grad.to(dt).float()
     assert torch.equal(got_dx, ref_dx)
     acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), dtype=torch.float32, device="cuda")
     call("mau_conv3x3_wgrad", xa.t.data_ptr(), xa.t.shape[-1], Cin, None, None, 0, dya.t.data_ptr(), dya.t.shape[-1], Cout,
@@ -132,6 +132,81 @@ def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
     call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin), dw.data_ptr(),
          Cout, Cin, st)
     assert torch.equal(dw.cpu(), w.grad)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 40, 19, 21, 0), (1, 64, 128, 64, 16, 16, 16), (3, 32, 8, 130, 40, 33, 0),
+                                   (2, 128, 64, 72, 70, 50, 8), (1, 16, 5, 8, 9, 7, 0)])
+def test_conv3x3_two_tensor_sources_bitwise(mau, dt, shape):
+    """Virtual channel concat (mau_conv3x3_fwd2 / mau_conv3x3_wgrad2): the convolution over [x | x1 | broadcast(emb)] read
+    from two tensors must equal, bit for bit, the convolution over the materialised concatenation (same K order), and
+    on small-integer data both must equal torch's conv2d exactly.  Reference: torch.cat([skip, up], 1) of
+    src/model.py:279-282 followed by VGGBlock's first convolution."""
+    from mau_amd import functional as F_
+    from mau_amd._lib import call, lib
+    N, C0, C1, Cout, H, W, E = shape
+    g = torch.Generator().manual_seed(sum(shape) + 7)
+    xa = torch.randint(-2, 3, (N, C0, H, W), generator=g).float()
+    xb = torch.randint(-2, 3, (N, C1, H, W), generator=g).float()
+    emb = torch.randint(-2, 3, (N, E), generator=g).float() if E else None
+    Cin = C0 + C1 + E
+    w = torch.randint(-2, 3, (Cout, Cin, 3, 3), generator=g).float()
+    b = torch.randint(-3, 4, (Cout,), generator=g).float()
+    dy = torch.randint(-2, 3, (N, Cout, H, W), generator=g).float()
+    parts = [xa, xb] + ([emb[:, :, None, None].expand(N, E, H, W)] if E else [])
+    xcat = torch.cat(parts, 1).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = TF.conv2d(xcat, wr, b, padding=1)
+    ref.backward(dy)
+    code = F_.dtype_code(dt)
+    st = torch.cuda.current_stream().cuda_stream
+    A, B, Cat = to_act(mau, xa, dt), to_act(mau, xb, dt), to_act(mau, torch.cat([xa, xb], 1), dt)
+    dya = to_act(mau, dy, dt)
+    wf = F_.pack_conv_weights(dev(w), code)[0]
+    embd = dev(emb) if E else None
+    ews = torch.empty((N, E), dtype=dt, device="cuda") if E else None
+    ld = F_.pad8(Cout)
+    y2 = torch.empty((N, H, W, ld), dtype=dt, device="cuda")
+    y1 = torch.empty_like(y2)
+    call("mau_conv3x3_fwd2", A.t.data_ptr(), A.t.shape[-1], C0, B.t.data_ptr(), B.t.shape[-1], C1, embd.data_ptr() if E else None,
+         ews.data_ptr() if E else None, E, wf.data_ptr(), dev(b).data_ptr(), None, None, y2.data_ptr(), ld, Cout, None, code, N, H, W, st)
+    call("mau_conv3x3_fwd", Cat.t.data_ptr(), Cat.t.shape[-1], C0 + C1, embd.data_ptr() if E else None, ews.data_ptr() if E else None, E,
+         wf.data_ptr(), dev(b).data_ptr(), None, None, y1.data_ptr(), ld, Cout, None, code, N, H, W, st)
+    assert torch.equal(y1, y2)
+    got = from_act(mau, F_.Act(y2, Cout))
+    lim = 256 if dt == torch.bfloat16 else 2048
+    assert torch.equal(got, ref.detach() if float(ref.abs().max()) < lim else ref.detach().to(dt).float())
+    ns = lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin)
+    acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), dtype=torch.float32, device="cuda")
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device="cuda")
+    call("mau_conv3x3_wgrad2", A.t.data_ptr(), A.t.shape[-1], C0, B.t.data_ptr(), B.t.shape[-1], C1, embd.data_ptr() if E else None,
+         ews.data_ptr() if E else None, E, dya.t.data_ptr(), dya.t.shape[-1], Cout, acc.data_ptr(), code, N, H, W, st)
+    call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), ns, dw.data_ptr(), Cout, Cin, st)
+    assert torch.equal(dw.cpu(), wr.grad)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 8), (1, 24, 9, 11), (3, 64, 31, 17), (2, 8, 2, 3)])
+def test_bn_relu_apply_pool_matches_two_passes(mau, dt, shape):
+    """mau_bn_relu_apply_pool == mau_bn_relu_apply followed by mau_maxpool2x2_fwd, bit for bit (odd sizes: floor pooling,
+    the uncovered last row / column still gets its activation)."""
+    from mau_amd import functional as F_
+    from mau_amd._lib import call
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    y = to_act(mau, torch.randn(N, C, H, W, generator=g), dt).t
+    sc, sh = dev(torch.randn(C, generator=g)), dev(torch.randn(C, generator=g))
+    code = F_.dtype_code(dt)
+    st = torch.cuda.current_stream().cuda_stream
+    ld = y.shape[-1]
+    a1, a2 = torch.empty_like(y), torch.empty_like(y)
+    p1 = torch.empty((N, H // 2, W // 2, ld), dtype=dt, device="cuda")
+    p2 = torch.empty_like(p1)
+    call("mau_bn_relu_apply", y.data_ptr(), ld, sc.data_ptr(), sh.data_ptr(), a1.data_ptr(), ld, code, N * H * W, C, st)
+    call("mau_maxpool2x2_fwd", a1.data_ptr(), ld, p1.data_ptr(), ld, code, N, H, W, C, st)
+    call("mau_bn_relu_apply_pool", y.data_ptr(), ld, sc.data_ptr(), sh.data_ptr(), a2.data_ptr(), ld, p2.data_ptr(), ld, code, N, H, W, C, st)
+    assert torch.equal(a1, a2) and torch.equal(p1, p2)
+
 
 
 def _vgg_from_golden(mau, d, prefix="sd0"):
@@ -249,19 +324,21 @@ def test_g3_fused_embedding_broadcast(mau, prec):
     ones, zeros = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
     # identity BatchNorm in eval mode (mean 0, var 1-eps) isolates the convolution: a = relu(conv + bias)
     st = F_.BNState(training=False, C0=sp.C, eps=0.0)
-    a = F_.ConvBNReLU.apply(sp.t, emb, w, b, ones.clone().requires_grad_(True), zeros.clone().requires_grad_(True),
+    a = F_.ConvBNReLU.apply(sp.t, None, emb, w, b, ones.clone().requires_grad_(True), zeros.clone().requires_grad_(True),
                             zeros.clone(), ones.clone(), None, st)
     yref = t(d["y"])
     assert err(from_act(mau, F_.Act(a, Cout)), torch.relu(yref)) < tol
     # gradient: upstream dy masked by relu on the reference side
     dy = t(d["dy"])
     spr, ter, mer = (t(d[k]).requires_grad_(True) for k in ("spatial", "t_emb", "m_emb"))
-    wr = t(d["weight"]).requires_grad_(True)
-    torch.relu(TF.conv2d(R.fuse_embeddings(spr, ter, mer), wr, t(d["bias"]), padding=1)).backward(dy)
+    wr, br = t(d["weight"]).requires_grad_(True), t(d["bias"]).requires_grad_(True)
+    torch.relu(TF.conv2d(R.fuse_embeddings(spr, ter, mer), wr, br, padding=1)).backward(dy)
     a.backward(to_act(mau, dy, dt).t)
     assert err(from_act(mau, F_.Act(sp.t.grad, sp.C)), spr.grad) < tol
     assert err(emb.grad.cpu(), torch.cat([ter.grad, mer.grad], 1)) < tol
     assert err(w.grad.cpu(), wr.grad) < tol
+    # eval-mode BatchNorm is a fixed affine map: the conv bias gets d/dbias = sum(dy) (it is identically zero only in train mode)
+    assert err(b.grad.cpu(), br.grad) < tol
 
 
 def test_g3_meta_mlp(mau):
