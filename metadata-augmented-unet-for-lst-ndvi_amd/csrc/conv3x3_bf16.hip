@@ -92,6 +92,36 @@ struct Geo {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
+// wave-uniform operands of the loader (see the kernel's "per-lane DMA slots" comment)
+struct LoaderArgs {
+  unsigned long long xa, x1a, wa, w_stage_bytes, zero_a;
+  unsigned ld0, ld1;
+  int C0, Ctot, E, lim0, lim1;
+  bool hasC1;
+};
+// Source address of one wave-DMA, selects only.  halo / chunk are wave-uniform: the tensor of a 16-channel stage, its
+// pixel stride and channel offset are computed on the scalar unit.  off32: halo slot = linear pixel index, weight slot =
+// element offset inside the chunk's slab, -1 = zero page.
+template <int KC_>
+__device__ __forceinline__ void dma_issue(const LoaderArgs la, unsigned long long embn_a, bool halo, int chunk, int slot_c, int off32,
+                                          unsigned char* lds_dst) {
+  const int c0 = chunk * KC_;
+  const bool second = la.hasC1 && c0 >= la.C0;
+  const unsigned long long ub = halo ? (second ? la.x1a : la.xa) : la.wa + (unsigned long long)chunk * la.w_stage_bytes;
+  const unsigned um = halo ? (second ? la.ld1 : la.ld0) : 1u;
+  const int ua = halo ? c0 - (second ? la.C0 : 0) : 0;
+  const int ulim = !halo ? 0x7fffffff : (second ? la.lim1 : la.lim0);
+  const int c = c0 + slot_c;
+  const int add = halo ? ua + slot_c : 0;
+  const bool valid = off32 >= 0;
+  const unsigned long long pt = ub + 2ull * ((unsigned long long)(unsigned)off32 * um + (unsigned long long)add);
+  const unsigned long long pe = embn_a + 2ull * (unsigned long long)(long long)(c - la.Ctot);
+  const bool is_t = valid & (c < ulim);
+  const bool is_e = valid & halo & ((unsigned)(c - la.Ctot) < (unsigned)la.E);
+  const unsigned long long src = is_t ? pt : (is_e ? pe : la.zero_a);
+  __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)lds_dst, 16, 0, 0);
+}
+
 template <int BN, int MT, int NW, int EPI, bool F16>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
   using G = Geo<BN, MT, NW>;
@@ -106,10 +136,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
   const int i32 = perm32(lane & 31), h = lane >> 5;   // tile row (pixel / channel) this lane's operands come from
 
   // (16-bit elements are only moved, never interpreted, outside the matrix core and the epilogue's conversion)
-  const unsigned short* __restrict__ xg = reinterpret_cast<const unsigned short*>(p.x);
-  const unsigned short* __restrict__ x1g = reinterpret_cast<const unsigned short*>(p.x1);
-  const unsigned short* __restrict__ wg = reinterpret_cast<const unsigned short*>(p.w);
-  const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero_page);
 
   // ---- work items: XCD-aware order; a persistent workgroup walks I = blockIdx.x, +gridDim.x, ...
   // (gridDim.x is a multiple of 8, so a workgroup stays on one XCD's slice of the item list) ----
@@ -170,9 +196,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
   // per-lane source offsets of the item being LOADED (constant over its stages); -1 = zero page
   //   halo slot: linear pixel index (n*H + gy)*W + gx;   weight slot: element offset of the row inside a chunk's slab
   int off32[PER_WAVE];
-  const unsigned short* embn = nullptr;
+  // the kernel arguments the loader needs, as plain scalars (the lambdas below must not keep the argument struct alive in memory)
+  const unsigned long long xa = (unsigned long long)p.x, x1a = (unsigned long long)p.x1, wa = (unsigned long long)p.w;
+  const unsigned long long zero_a = (unsigned long long)g_zero_page, emb_a = (unsigned long long)p.emb_lp;
+  const int C0v = p.C0, Ev = p.E, Hv = p.H, Wv = p.W, CoutPadv = p.CoutPad;
+  const bool hasC1 = p.C1 > 0;
+  const unsigned ld0v = (unsigned)p.ldx, ld1v = (unsigned)p.ldx1;
+  const int lim0v = (p.C1 == 0 && p.E == 0) ? p.ldx : p.C0, lim1v = p.E == 0 ? p.C0 + p.ldx1 : p.C0 + p.C1;
+  unsigned long long embn_a = 0;
   auto setup = [&](const Item& it) {
-    embn = reinterpret_cast<const unsigned short*>(p.emb_lp) + (size_t)it.n * p.E;
+    embn_a = emb_a + 2ull * (unsigned long long)((long long)it.n * Ev);
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
       const int q = wave + j * NW;
@@ -181,43 +214,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
         const int hp = slot_hp[j];
         if (hp >= 0) {
           const int gy = it.ty0 + hp / HS - 1, gx = it.tx0 + hp % HS - 1;
-          if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) off32[j] = (it.n * p.H + gy) * p.W + gx;
+          if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv) off32[j] = (it.n * Hv + gy) * Wv + gx;
         }
       } else if (q < TOT_Q) {
         const int row = slot_hp[j];
         // (the packed rows are pre-permuted: row nt*32 + i of a 64-channel block holds output channel 2*i + nt, so the
         // two accumulator tiles of a lane carry ADJACENT channels -- pack_weights_kernel, conv3x3.hip)
         const int tap = row / BN, co = row % BN;
-        off32[j] = (tap * p.CoutPad + it.co0 + co) * KC + slot_c[j];
+        off32[j] = (tap * CoutPadv + it.co0 + co) * KC + slot_c[j];
       }
     }
   };
   // one wave-DMA (1 KiB) of a stage; j is a compile-time constant after unrolling.  Everything that depends only on
   // (slot kind, chunk) is wave-uniform and computed on the scalar unit.
-  auto issue_slot = [&](int j, int stage, int chunk) {
-    const int q = wave + j * NW;                      // wave-uniform
-    const bool halo = q < HALO_Q;
-    const int c0 = chunk * KC;
-    const bool second = p.C1 > 0 && c0 >= p.C0;
-    const unsigned short* ub = halo ? (second ? x1g : xg) : wg + (size_t)chunk * w_stage_stride;
-    const unsigned um = halo ? (unsigned)(second ? p.ldx1 : p.ldx) : 1u;
-    const int ua = halo ? c0 - (second ? p.C0 : 0) : 0;
-    const int ulim = !halo ? 0x7fffffff
-                           : (second ? (p.E == 0 ? p.C0 + p.ldx1 : Ctot) : ((p.C1 == 0 && p.E == 0) ? p.ldx : p.C0));
-    const int c = c0 + slot_c[j];
-    const int add = halo ? ua + slot_c[j] : 0;
-    const bool valid = off32[j] >= 0;
-    const unsigned short* pt = ub + ((size_t)(unsigned)off32[j] * um + (size_t)add);
-    const unsigned short* pe = embn + (c - Ctot);
-    const bool is_t = valid & (c < ulim);
-    const bool is_e = valid & halo & ((unsigned)(c - Ctot) < (unsigned)p.E);
-    const unsigned short* src = is_t ? pt : (is_e ? pe : zero);
-    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + stage * STAGE + q * 1024), 16, 0, 0);
-  };
-  auto issue = [&](int stage, int chunk) {
-#pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) issue_slot(j, stage, chunk);
-  };
+  // One wave-DMA (1 KiB) of a stage: dma_issue() below, a plain function with every operand passed BY VALUE.  (As a
+  // [&] lambda, "halo ? (second ? x1 : x) : w" became a load from a SELECTED field of the closure object, which pinned the
+  // closure -- and with it wave, slot_c[], off32[] -- in private memory: 300 bytes of scratch traffic inside the K loop.)
+  const LoaderArgs la = {xa, x1a, wa, 2ull * w_stage_stride, zero_a, ld0v, ld1v, C0v, Ctot, Ev, lim0v, lim1v, hasC1};
+#define MAU_ISSUE_SLOT(J, STAGE_, CHUNK_)                                                                              \
+  dma_issue<KC>(la, embn_a, wave + (J) * NW < HALO_Q, (CHUNK_), slot_c[(J)], off32[(J)],                              \
+                smem + (STAGE_) * STAGE + (wave + (J) * NW) * 1024)
 
   // ---- per-lane LDS read addresses: three bases (one per dx) + immediates for (mt, dy); two for the weights ----
   int abase[3];
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
   int I = next_valid(blockIdx.x, cur);
   if (I < 0) return;                                  // whole workgroup leaves before any barrier
   setup(cur);
-  issue(0, 0);
+  static_for<0, PER_WAVE>([&](auto jc) { MAU_ISSUE_SLOT(decltype(jc)::value, 0, 0); });
   int stage = 0;
   unsigned short* __restrict__ yg = reinterpret_cast<unsigned short*>(p.y);
 
@@ -296,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     }                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                \
     if constexpr ((T) < PER_WAVE) {                                                   \
-      issue_slot((T), stage ^ 1, fchunk);                                             \
+      MAU_ISSUE_SLOT((T), stage ^ 1, fchunk);                                         \
       __builtin_amdgcn_sched_barrier(0);                                              \
     }                                                                                 \
   }
@@ -408,6 +424,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     I = In;
   }
   wait_vmcnt<0>();                                     // the idle re-fetch of the last stage must land before the LDS is released
+#undef MAU_ISSUE_SLOT
 }
 
 template <int BN, int MT, int NW, int EPI, bool F16>
