@@ -232,6 +232,21 @@ int mau_meta_mlp_bwd(const float* md, const float* w0, const float* w2, const fl
                      const float* demb, float* dw0, float* db0, float* dw2, float* db2, float* dhidden_ws,
                      int N, int F, int Hd, int D, mau_stream_t stream);
 
+/* ---- TemporalEncoder recurrence: nn.LSTM(input_size=1, hidden_size=H, batch_first=True), last hidden state
+ *      (src/model.py:23-34; the sequence is 828 monthly temperatures in the reference's data, conf/config.yaml:20) ---- */
+/* Largest hidden size the persistent kernels support (one gate row per thread). */
+int mau_lstm_max_hidden(void);
+/* x (B,T) fp32; w_ih (4H) [input_size 1], w_hh (4H,H), b_ih, b_hh (4H): torch's parameter layout, gate order i,f,g,o.
+ * h_last (B,H) = h_T.  gates (B,T,4H) post-activation and cells (B,T,H), both or neither: saved for mau_lstm_bwd. */
+int mau_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                 float* h_last, float* gates, float* cells, int B, int T, int H, mau_stream_t stream);
+/* dh_last (B,H) -> dw_ih (4H), dw_hh (4H,H), db_ih = db_hh (4H); ws: fp32 workspace of mau_lstm_bwd_ws_elems(B,T,H)
+ * elements (pre-activation gate gradients of every step + partial sums, added in a fixed order). */
+size_t mau_lstm_bwd_ws_elems(int B, int T, int H);
+int mau_lstm_bwd(const float* x, const float* w_hh, const float* gates, const float* cells, const float* dh_last,
+                 float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* ws, int B, int T, int H,
+                 mau_stream_t stream);
+
 /* ---- loss: F.mse_loss (src/utils/losses.py:27-39) -------------------------- */
 /* loss[0] = mean((out-tgt)^2) (fp64 accumulation, fixed order); dout (optional) = 2*(out-tgt)/n;
  * partial: fp64 workspace of mau_mse_blocks(n) elements. */
@@ -246,6 +261,15 @@ int mau_mse_fwd_bwd(const float* out, const float* tgt, double* partial, float* 
 int mau_l1_gradient_blocks(int64_t n);
 int mau_l1_gradient_loss(const float* out, const float* tgt, double* partial, float* terms, float* dout, float w_l1,
                          float w_grad, int B, int C, int H, int W, mau_stream_t stream);
+
+/* ---- SSIM term of compute_loss_l1_grad_ssim (src/utils/losses.py:70-97; piq.ssim defaults, PARITY UNPINNED: piq is
+ *      not available to generate a fixture; value only -- the reference detaches it at :96) ---- */
+/* out/tgt (B,C,H,W) fp32.  prep != 0 applies the reference's channel preparation while loading (:72-84): channel 0 ->
+ * (v+1)/2, channel 1 -> clamp(v,0,1).  per_image (B) = SSIM per sample (mean over channels), loss[0] = 1 - mean(per_image).
+ * ws: fp64 workspace of mau_ssim_ws_elems(B,C,H,W) elements (per-tile sums, added in a fixed order). */
+size_t mau_ssim_ws_elems(int B, int C, int H, int W);
+int mau_ssim_loss(const float* out, const float* tgt, double* ws, float* per_image, float* loss, int prep, int B, int C,
+                  int H, int W, mau_stream_t stream);
 
 #ifdef __cplusplus
 }

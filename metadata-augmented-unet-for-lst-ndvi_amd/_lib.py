@@ -71,9 +71,15 @@ PROTOTYPES = {
     "mau_head_bwd_rowlen": (_i, [_i, _i]),
     "mau_meta_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mau_meta_mlp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mau_lstm_max_hidden": (_i, []),
+    "mau_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "mau_lstm_bwd_ws_elems": (_sz, [_i, _i, _i]),
+    "mau_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "mau_mse_blocks": (_i, [_i64]),
     "mau_l1_gradient_blocks": (_i, [_i64]),
     "mau_l1_gradient_loss": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i, _i, _i, _p]),
+    "mau_ssim_ws_elems": (_sz, [_i, _i, _i, _i]),
+    "mau_ssim_loss": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mau_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _i64, _p]),
 }
 

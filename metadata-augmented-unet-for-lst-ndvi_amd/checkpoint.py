@@ -5,7 +5,7 @@
   (``model_type`` default 'unet', ``metadata_input_length`` default 4, legacy keys
   ``additional_embeddings`` / ``metadata_only_embeddings`` / ``'noemb'`` study names, and the
   ``model_state_dict`` | ``state_dict`` | bare state-dict variants).
-Files are interchangeable with the reference in both directions (same keys, shapes, dtypes).
+Files are interchangeable with the reference in both directions (same keys, value types, tensor shapes and dtypes).
 """
 from __future__ import annotations
 
@@ -18,11 +18,12 @@ from .model import UrbanPredictor
 
 
 def build_hyperparameters(cfg, model_type: str, temporal_embeddings: bool, metadata_embeddings: bool,
-                          input_channels: int, target_channels) -> Dict[str, Any]:
-    """``hyperparams`` dict of src/train.py:156-168."""
+                          input_channels, target_channels) -> Dict[str, Any]:
+    """``hyperparams`` dict of src/train.py:156-168, field for field: ``target_channels`` and ``input_channels`` are the
+    comma-joined channel NAMES of ``CONFIG.dataset`` (strings), exactly as the reference writes them."""
     return {"learning_rate": cfg.learning_rate, "batch_size": cfg.batch_size, "weight_decay": cfg.weight_decay,
             "temporal_dim": cfg.temporal_dim, "meta_dim": cfg.meta_dim, "lstm_hidden": cfg.lstm_hidden,
-            "model_type": model_type, "target_channels": list(target_channels), "input_channels": input_channels,
+            "model_type": model_type, "target_channels": ",".join(target_channels), "input_channels": ",".join(input_channels),
             "temporal_embeddings": temporal_embeddings, "metadata_embeddings": metadata_embeddings}
 
 

@@ -42,9 +42,9 @@ def load_config(path: str = DEFAULT_YAML) -> AttrDict:
     for k in ("learning_rate", "weight_decay", "momentum"):      # "1e-4" parses as a string in YAML 1.1
         if k in t:
             t[k] = float(t[k])
-    cfg.MODELS_DIR = os.path.join(ROOT, "models")                # urban_planner/config.py:26-29 analogue
+    cfg.MODELS_DIR = os.environ.get("MAU_MODELS_DIR") or os.path.join(ROOT, "models")   # urban_planner/config.py:26-29 analogue
     cfg.device = "cuda:0"                                        # injected by the CLI, as in the reference
     return cfg
 
 
-CONFIG = load_config()
+CONFIG = load_config(os.environ.get("MAU_CONFIG") or DEFAULT_YAML)

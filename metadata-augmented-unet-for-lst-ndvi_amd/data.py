@@ -281,5 +281,15 @@ def create_dataloader(split: str, batch_size: int, shuffle: bool, dataset_type: 
     ``device`` the result is a :class:`DeviceLoader` yielding the reference's 7-tuple with packed inputs."""
     assert dataset_type == "future", "Only 'future' dataset_type is supported in create_dataloader."
     ds = FuturePredictionDataset(split=split, transform=transform, processed_dir=processed_dir, compact=True)
-    dl = DataLoader(ds, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers, collate_fn=collate_fn)
+    sampler, drop_last = None, False
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # data parallel: every rank must run the SAME number of steps (one BatchNorm / gradient collective per layer and
+        # step, a missing partner deadlocks) on equally sized local batches -> disjoint equal shards, ragged tail dropped
+        # (SyncBN itself tolerates unequal local batch sizes: the pixel count travels with the statistics)
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(ds, shuffle=shuffle, drop_last=True)
+        shuffle, drop_last = False, True
+    dl = DataLoader(ds, batch_size=batch_size, shuffle=shuffle, sampler=sampler, drop_last=drop_last, num_workers=num_workers,
+                    collate_fn=collate_fn)
     return DeviceLoader(dl, device, dtype) if device is not None else dl

@@ -258,7 +258,9 @@ class ConvBNReLU(torch.autograd.Function):
             # eval-mode BN + ReLU are a fixed per-channel affine map -> folded into the conv epilogue.  In a frozen
             # session (UrbanPredictor.freeze_inference) the packed weights and the folded coefficients are computed once.
             fz = st.frozen if st.frozen is not None else {}
-            if "wf" not in fz or fz["wf"].dtype != x.dtype:
+            fkey = (_GENERATION[0], weight._version, gamma._version, rmean._version, rvar._version)
+            if "wf" not in fz or fz["wf"].dtype != x.dtype or fz.get("key") != fkey:
+                fz["key"] = fkey        # (an optimizer step, mark_params_updated() or any in-place write re-derives the copies)
                 fz["wf"] = pack_conv_weights(weight, code, forward=True, dgrad=False)[0]
                 fz["scale"], fz["shift"] = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
                 call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
@@ -727,6 +729,48 @@ class MetaMLP(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- #
+# TemporalEncoder recurrence
+# --------------------------------------------------------------------------- #
+class LSTMLast(torch.autograd.Function):
+    """h_T of nn.LSTM(input_size=1, hidden_size=H, batch_first=True) over x (B,T) (src/model.py:26,30-31: ``_, (h_n, _) =
+    self.lstm(x.unsqueeze(-1))``; ``h_n[-1]``), the whole sequence in one persistent launch per direction.
+    Parameters in torch's layout: weight_ih_l0 (4H,1), weight_hh_l0 (4H,H), bias_ih_l0, bias_hh_l0 (4H)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        _require_cuda(x, "TemporalEncoder")
+        x = x.contiguous().float()
+        B, T = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        need = any(ctx.needs_input_grad[1:])
+        h = torch.empty((B, H), dtype=torch.float32, device=dev)
+        gates = torch.empty((B, T, 4 * H), dtype=torch.float32, device=dev) if need else None
+        cells = torch.empty((B, T, H), dtype=torch.float32, device=dev) if need else None
+        wi, wh = w_ih.detach().contiguous().float(), w_hh.detach().contiguous().float()
+        call("mau_lstm_fwd", x.data_ptr(), wi.data_ptr(), wh.data_ptr(), b_ih.detach().data_ptr(), b_hh.detach().data_ptr(),
+             h.data_ptr(), gates.data_ptr() if need else None, cells.data_ptr() if need else None, B, T, H, _stream())
+        if need:
+            ctx.save_for_backward(x, wh, gates, cells)
+        ctx.shapes = (tuple(w_ih.shape), B, T, H)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, wh, gates, cells = ctx.saved_tensors
+        wshape, B, T, H = ctx.shapes
+        dev = x.device
+        dh = dh.contiguous().float()
+        f32 = dict(dtype=torch.float32, device=dev)
+        dw_ih, dw_hh = torch.empty(4 * H, **f32), torch.empty((4 * H, H), **f32)
+        db_ih, db_hh = torch.empty(4 * H, **f32), torch.empty(4 * H, **f32)
+        ws = torch.empty(lib.mau_lstm_bwd_ws_elems(B, T, H), **f32)
+        call("mau_lstm_bwd", x.data_ptr(), wh.data_ptr(), gates.data_ptr(), cells.data_ptr(), dh.data_ptr(), dw_ih.data_ptr(),
+             dw_hh.data_ptr(), db_ih.data_ptr(), db_hh.data_ptr(), ws.data_ptr(), B, T, H, _stream())
+        return None, dw_ih.view(wshape), dw_hh, db_ih, db_hh            # (the series is data: no gradient w.r.t. x)
+
+
+# --------------------------------------------------------------------------- #
 # MSE criterion
 # --------------------------------------------------------------------------- #
 class MSELoss(torch.autograd.Function):
@@ -743,47 +787,44 @@ class MSELoss(torch.autograd.Function):
         dout = torch.empty_like(out) if ctx.needs_input_grad[0] else None
         call("mau_mse_fwd_bwd", out.data_ptr(), tgt.data_ptr(), partial.data_ptr(), loss.data_ptr(),
              dout.data_ptr() if dout is not None else None, n, _stream())
-        ctx.dout = dout
+        ctx.save_for_backward(dout)                      # kept across backward calls (retain_graph works)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        d = ctx.dout
-        ctx.dout = None
-        return d * g, None
+        (d,) = ctx.saved_tensors
+        return (d * g if d is not None else None), None
 
 
 class L1GradientLoss(torch.autograd.Function):
-    """(mean|o-t|, gradient_loss(o,t)) of src/utils/losses.py:5-25,68 and, for backward, the gradient of
-    ``w_l1 * l1 + w_grad * gradient_loss`` produced in the same pass."""
+    """(mean|o-t|, gradient_loss(o,t)) of src/utils/losses.py:5-25,68.  The two outputs are independent autograd values, as
+    in the reference: backward returns ``g_l1 * d l1/d out + g_grad * d gradient_loss/d out`` for WHATEVER weights the
+    caller combines them with (the two partial gradients are produced by two passes of the same kernel)."""
 
     @staticmethod
-    def forward(ctx, out, tgt, w_l1: float, w_grad: float):
+    def forward(ctx, out, tgt):
         _require_cuda(out, "gradient_loss")
         out = out.contiguous().float()
         tgt = tgt.contiguous().float()
         B, Cc, H, W = out.shape
         n = out.numel()
+        need = ctx.needs_input_grad[0]
         partial = torch.empty(3 * lib.mau_l1_gradient_blocks(n), dtype=torch.float64, device=out.device)
         terms = torch.empty(3, dtype=torch.float32, device=out.device)
-        dout = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        d_l1 = torch.empty_like(out) if need else None
+        d_gr = torch.empty_like(out) if need else None
         call("mau_l1_gradient_loss", out.data_ptr(), tgt.data_ptr(), partial.data_ptr(), terms.data_ptr(),
-             dout.data_ptr() if dout is not None else None, float(w_l1), float(w_grad), B, Cc, H, W, _stream())
-        ctx.dout = dout
-        ctx.w = (float(w_l1), float(w_grad))
-        l1 = terms[0]
-        grad_loss = terms[1] + terms[2]
-        return l1, grad_loss
+             d_l1.data_ptr() if need else None, 1.0, 0.0, B, Cc, H, W, _stream())
+        if need:
+            terms2 = torch.empty(3, dtype=torch.float32, device=out.device)
+            call("mau_l1_gradient_loss", out.data_ptr(), tgt.data_ptr(), partial.data_ptr(), terms2.data_ptr(),
+                 d_gr.data_ptr(), 0.0, 1.0, B, Cc, H, W, _stream())
+        ctx.save_for_backward(d_l1, d_gr)
+        return terms[0], terms[1] + terms[2]
 
     @staticmethod
     def backward(ctx, g_l1, g_grad):
-        # dout already holds d(w_l1*l1 + w_grad*grad)/dout; callers combine the two outputs with exactly these weights
-        d = ctx.dout
-        ctx.dout = None
-        w_l1, w_grad = ctx.w
-        scale = None
-        if w_l1 != 0.0:
-            scale = g_l1 / w_l1
-        elif w_grad != 0.0:
-            scale = g_grad / w_grad
-        return (d * scale if scale is not None else torch.zeros_like(d)), None, None, None
+        d_l1, d_gr = ctx.saved_tensors
+        if d_l1 is None:
+            return None, None
+        return g_l1 * d_l1 + g_grad * d_gr, None

@@ -5,16 +5,19 @@
 * ``compute_loss_mse_gradient``   :41-57   mse + 0.1 * gradient
 * ``compute_loss_l1_grad_ssim``   :59-99   l1 + 0.1 * gradient + 0.5 * (1 - ssim)       (the yaml default, conf/config.yaml:42)
 
-In the reference the SSIM values pass through ``torch.Tensor(ssim_vals)`` (:96), which detaches them: the SSIM
+In the reference the SSIM values pass through ``torch.Tensor(ssim_vals)`` (:89-96), which detaches them: the SSIM
 term changes the reported number, never the gradient.  ``piq`` (the SSIM provider) is not available in the
-build environment, so the SSIM VALUE below follows piq's published default algorithm (11x11 Gaussian, sigma
-1.5, k1 0.01, k2 0.03, average-pool downsampling by max(1, round(min(H, W)/256))) with plain torch ops and is
-**parity-unpinned**; everything that carries gradient is pinned by fixture ``g9_losses.npz``.
+build environment, so the SSIM VALUE follows piq's published default algorithm (11x11 Gaussian, sigma 1.5,
+k1 0.01, k2 0.03, average-pool downsampling by max(1, round(min(H, W)/256))): one fused HIP reduction
+(``mau_ssim_loss``, csrc/ssim.hip), checked on the GPU against the torch-op spelling ``ssim_value_torch`` below.
+That scalar is **parity-unpinned** (no reference fixture can be generated without piq); everything that carries
+gradient is pinned by fixture ``g9_losses.npz``.
 """
 import torch
 import torch.nn.functional as F
 
-from .functional import L1GradientLoss, MSELoss
+from .functional import L1GradientLoss, MSELoss, _require_cuda, _stream
+from ._lib import call, lib
 
 
 def compute_loss_mse(outputs, targets):
@@ -25,19 +28,35 @@ def compute_loss_mse(outputs, targets):
 
 def gradient_loss(pred, target):
     """src/utils/losses.py:5-25."""
-    _, g = L1GradientLoss.apply(pred, target, 0.0, 1.0)
+    _, g = L1GradientLoss.apply(pred, target)
     return {"gradient": g}
 
 
 def compute_loss_mse_gradient(outputs, targets, lambda_grad=0.1):
     """src/utils/losses.py:41-57."""
     mse = MSELoss.apply(outputs, targets)
-    _, g = L1GradientLoss.apply(outputs, targets, 0.0, lambda_grad)
+    _, g = L1GradientLoss.apply(outputs, targets)
     return {"total": mse + lambda_grad * g, "mse": mse, "gradient": g}
 
 
-def _ssim_value(x, y, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
-    """Per-image SSIM averaged over channels (piq.ssim defaults, reduction='none'); reporting only, no gradient."""
+def ssim_loss(outputs, targets):
+    """1 - mean over the batch of piq.ssim(prepared outputs, prepared targets) (src/utils/losses.py:72-97) in one HIP
+    reduction; the channel preparation (:72-84) happens while the tiles are loaded.  Value only (no gradient), parity
+    unpinned (module docstring).  Returns (loss scalar, per-image SSIM (B,))."""
+    _require_cuda(outputs, "compute_loss_l1_grad_ssim")
+    o = outputs.detach().contiguous().float()
+    t = targets.detach().contiguous().float()
+    B, C, H, W = o.shape
+    ws = torch.empty(lib.mau_ssim_ws_elems(B, C, H, W), dtype=torch.float64, device=o.device)
+    per_image = torch.empty(B, dtype=torch.float32, device=o.device)
+    loss = torch.empty(1, dtype=torch.float32, device=o.device)
+    call("mau_ssim_loss", o.data_ptr(), t.data_ptr(), ws.data_ptr(), per_image.data_ptr(), loss.data_ptr(), 1, B, C, H, W, _stream())
+    return loss.reshape(()), per_image
+
+
+def ssim_value_torch(x, y, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
+    """The same quantity spelled with torch ops (the checker of the HIP kernel in tests/): per-image SSIM averaged over
+    channels (piq.ssim defaults, reduction='none')."""
     with torch.no_grad():
         x, y = x / data_range, y / data_range
         f = max(1, round(min(x.shape[-2:]) / 256))
@@ -60,9 +79,7 @@ def _ssim_value(x, y, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0.0
 
 def compute_loss_l1_grad_ssim(outputs, targets, lambda_grad=0.1, lambda_ssim=0.5):
     """src/utils/losses.py:59-99 (same dict keys).  Gradient = d(l1 + lambda_grad*gradient); SSIM is value-only."""
-    l1, g = L1GradientLoss.apply(outputs, targets, 1.0, lambda_grad)
-    o = torch.stack([(outputs[:, 0] + 1.0) / 2.0, torch.clamp(outputs[:, 1], 0.0, 1.0)], dim=1).detach()   # :72-84
-    t = torch.stack([(targets[:, 0] + 1.0) / 2.0, torch.clamp(targets[:, 1], 0.0, 1.0)], dim=1).detach()
-    ssim_loss = 1 - _ssim_value(o, t, data_range=1.0).mean()                                                # :88-89
-    total = l1 + lambda_grad * g + lambda_ssim * ssim_loss
-    return {"total": total, "pixel": l1, "gradient": g, "ssim": ssim_loss}
+    l1, g = L1GradientLoss.apply(outputs, targets)
+    s, _ = ssim_loss(outputs, targets)                                                                     # :72-97
+    total = l1 + lambda_grad * g + lambda_ssim * s
+    return {"total": total, "pixel": l1, "gradient": g, "ssim": s}

@@ -9,7 +9,7 @@ checkpoints load with ``strict=True``) and error behaviour:
     UrbanPredictor_unetpp     src/model.py:51-193
     VGGBlock                  src/model.py:9-21
     MetadataEncoder           src/model.py:38-48
-    TemporalEncoder           src/model.py:23-34   (LSTM stays torch.nn.LSTM)
+    TemporalEncoder           src/model.py:23-34   (the LSTM recurrence is one persistent HIP launch per direction)
 
 The ``torch.nn`` layers inside are parameter containers created in the reference's order (so the
 same ``torch.manual_seed`` gives the same initial weights); their ``forward`` is never used for
@@ -67,6 +67,13 @@ class VGGBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self._rt: Optional[_Runtime] = None
         self._frozen = None               # [dict, dict] while a frozen inference session is active
+        # a state-dict load through ANY container (nn.Module recursion calls _load_from_state_dict, not load_state_dict)
+        # drops the frozen copies: they would keep serving the old weights and BatchNorm coefficients
+        self._register_load_state_dict_pre_hook(self._drop_frozen)
+
+    def _drop_frozen(self, *_args, **_kwargs):
+        if self._frozen is not None:
+            self._frozen = [{}, {}]
 
     def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d, x1: Optional[Act] = None, pool: bool = False):
         rt = self._rt or _Runtime()
@@ -96,8 +103,14 @@ class TemporalEncoder(nn.Module):
         self.fc = nn.Linear(hidden_dim, out_dim)
 
     def forward(self, x):
-        _, (h_n, _) = self.lstm(x.unsqueeze(-1))
-        return self.fc(h_n[-1])
+        lstm = self.lstm
+        if lstm.hidden_size <= F_.lib.mau_lstm_max_hidden():
+            # the whole (up to 828-step, conf/config.yaml:20) recurrence in one persistent HIP launch per direction
+            h = F_.LSTMLast.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
+        else:   # hidden sizes beyond one gate row per thread: the library LSTM (SURVEY 8a row a19 allows it)
+            _, (h_n, _) = lstm(x.unsqueeze(-1))
+            h = h_n[-1]
+        return torch.nn.functional.linear(h, self.fc.weight, self.fc.bias)
 
 
 class MetadataEncoder(nn.Module):

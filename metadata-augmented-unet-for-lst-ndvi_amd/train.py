@@ -42,6 +42,16 @@ def main(device: str = "", wandblog: bool = False, n_trials: int = 1, force_stud
          temporal_embeddings: bool = True, metadata_embeddings: bool = True, study_name: str = "urban-predictor",
          model_type: str = "unet++", jobid: str = "", epochs: Optional[int] = None, steps_per_epoch: int = 20,
          precision: str = "bf16"):
+    """The reference's CLI (src/train.py:62-73) + --epochs / --steps-per-epoch / --precision."""
+    return run(device, wandblog, n_trials, force_study_name, temporal_embeddings, metadata_embeddings, study_name, model_type,
+               jobid, epochs, steps_per_epoch, precision)["best"]
+
+
+def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study_name: bool = False,
+        temporal_embeddings: bool = True, metadata_embeddings: bool = True, study_name: str = "urban-predictor",
+        model_type: str = "unet++", jobid: str = "", epochs: Optional[int] = None, steps_per_epoch: int = 20,
+        precision: str = "bf16"):
+    """Body of the CLI as a function; returns {'best', 'model', 'optimizer', 'checkpoint_path'}."""
     assert model_type in ["unet", "unet++"], "model_type must be 'unet' or 'unet++'"          # src/train.py:78
     if not force_study_name:                                                                  # src/train.py:79-87
         study_name += "-emb" if temporal_embeddings and metadata_embeddings else "-tempemb" if temporal_embeddings \
@@ -82,9 +92,9 @@ def main(device: str = "", wandblog: bool = False, n_trials: int = 1, force_stud
         model.set_sync_bn(dist.group.WORLD)
         sync = GradSync(model)
     hyper = build_hyperparameters(cfg, model_type, temporal_embeddings, metadata_embeddings,
-                                  CONFIG.dataset.nb_input_channels, CONFIG.dataset.target_channels)
+                                  CONFIG.dataset.input_channels, CONFIG.dataset.target_channels)
     gen = torch.Generator().manual_seed(CONFIG.seed + rank)
-    best, step = float("inf"), 0
+    best, step, ckpt_path = float("inf"), 0, None
     for epoch in range(epochs if epochs is not None else cfg.epochs):
         model.train()
         total = 0.0
@@ -110,10 +120,11 @@ def main(device: str = "", wandblog: bool = False, n_trials: int = 1, force_stud
             if epoch_loss < best:                                                           # src/train.py:303-319
                 best = epoch_loss
                 name = f"{study_name}_trial_0_best_job{jobid}.pth"
-                save_checkpoint(os.path.join(CONFIG.MODELS_DIR, name), model, optimizer, epoch=epoch, step=step, loss=best,
+                ckpt_path = os.path.join(CONFIG.MODELS_DIR, name)
+                save_checkpoint(ckpt_path, model, optimizer, epoch=epoch, step=step, loss=best,
                                 hyperparameters=hyper, model_type=model_type, study_name=study_name, trial_id=0,
                                 metadata_input_length=n_meta)
-    return best
+    return {"best": best, "model": model, "optimizer": optimizer, "checkpoint_path": ckpt_path}
 
 
 if __name__ == "__main__":

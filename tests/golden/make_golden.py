@@ -9,7 +9,7 @@ Imports ``/root/reference/src/model.py`` (with a no-op ``loguru`` stub: loguru i
 not installed and is used for one log line, src/model.py:202), runs the
 reference modules on seeded inputs on the CPU and writes inputs + expected
 outputs as ``.npz`` (fp32).  No reference source is copied: fixtures are data.
-The fixture ids follow SURVEY.md 8(c): G1..G8 (+ G9 losses, G10 deep supervision).
+The fixture ids follow SURVEY.md 8(c): G1..G8 (+ G9 losses, G10 deep supervision, G11 TemporalEncoder at T=828).
 """
 import contextlib
 import io
@@ -302,12 +302,26 @@ def g10_deep_supervision(ref):
         **sd_arrays("sd0", sd0), **grads)
 
 
+def g11_temporal_encoder_828(ref):
+    """TemporalEncoder (src/model.py:23-34) at the reference's real sequence length (conf/config.yaml:20 temporal_length 828),
+    hidden 96 -> 64 as in conf/config.yaml:46-47: last-hidden embedding and every parameter gradient."""
+    torch.manual_seed(111)
+    enc = ref.TemporalEncoder(828, hidden_dim=96, out_dim=64)
+    g = torch.Generator().manual_seed(112)
+    ts = torch.randn(3, 828, generator=g)
+    emb = enc(ts)
+    demb = torch.randn(emb.shape, generator=g)
+    emb.backward(demb)
+    npz("g11_temporal_828.npz", ts=ts, emb=emb, demb=demb, **sd_arrays("sd", enc.state_dict()),
+        **{f"grad/{k}": p.grad for k, p in enc.named_parameters()})
+
+
 def main():
     ref = import_reference()
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                      # regenerate selected fixtures only: make_golden.py g10 ...
         for name in sys.argv[1:]:
-            fn = {"g10": lambda: g10_deep_supervision(ref)}[name]
+            fn = {"g10": lambda: g10_deep_supervision(ref), "g11": lambda: g11_temporal_encoder_828(ref)}[name]
             fn()
         return
     g1_vgg(ref)
@@ -326,6 +340,7 @@ def main():
     g8_syncbn(ref)
     g9_losses()
     g10_deep_supervision(ref)
+    g11_temporal_encoder_828(ref)
 
 
 if __name__ == "__main__":

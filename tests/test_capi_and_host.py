@@ -236,3 +236,17 @@ def test_dataset_and_collate_mirror_the_reference_contract(tmp_path):
         assert np.array_equal(x, ref_like[i][0].numpy())
     dense_bytes = 3 * (23 + 2) * 20 * 18 * 4
     assert batch.host_bytes() < 0.4 * dense_bytes
+
+
+def test_asan_host_build_of_the_c_abi():
+    """`make asan` (csrc/Makefile): the library's HOST code (argument validation, size helpers, error reporting) built
+    with -fsanitize=address, driven by tests/asan_host_check.c -- every size helper and one refused call per entry-point
+    family -- without a GPU.  (No GPU-side sanitizer exists on this pool: SURVEY section 5.)"""
+    import shutil
+    import subprocess
+    if not os.path.exists(subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()) \
+            or shutil.which("make") is None:
+        pytest.skip("no libasan / make in this environment")
+    csrc = os.path.join(ROOT, "metadata-augmented-unet-for-lst-ndvi_amd", "csrc")
+    p = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "asan host check OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

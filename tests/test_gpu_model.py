@@ -587,3 +587,38 @@ def test_bf16_sane_on_constructor_matrix(mau, cfg):
             n_ours += float((p.grad.double() ** 2).sum())
             n_ref += float((sd[k].grad.double() ** 2).sum())
     assert not well_conditioned or abs((n_ours / n_ref) ** 0.5 - 1.0) < 0.3
+
+
+def test_train_cli_writes_reference_checkpoint_and_reloads(mau, tmp_path):
+    """two steps of ``mau_amd.train`` at the reference's production configuration (conf/config.yaml: 23
+    channels, 250x250 tiles, 8 metadata features, B=16, l1-gradient-ssim loss, AdamW) write the ``.pth`` of
+    src/train.py:303-319; ``checkpoint.load_model`` (the rules of app/model_utils.py:16-100) must rebuild a model whose
+    eval output equals the trained model's bit for bit, and the dict must carry the reference's keys and value types."""
+    from mau_amd import checkpoint, train
+    from mau_amd.config import CONFIG
+    old = CONFIG.MODELS_DIR
+    CONFIG.MODELS_DIR = str(tmp_path)
+    try:
+        res = train.run(device="gpu", temporal_embeddings=False, metadata_embeddings=True, model_type="unet", jobid="t",
+                        epochs=1, steps_per_epoch=2, precision="bf16")
+    finally:
+        CONFIG.MODELS_DIR = old
+    path = res["checkpoint_path"]
+    assert path is not None and path.endswith("urban-predictor-metaemb_trial_0_best_jobt.pth")
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "step", "model_state_dict", "optimizer_state_dict", "loss", "hyperparameters", "model_type",
+                       "study_name", "trial_id", "metadata_input_length"}
+    hp = ck["hyperparameters"]
+    assert hp["target_channels"] == "after_ndvi,after_temp" and isinstance(hp["input_channels"], str) and "before_dw" in hp["input_channels"]
+    assert ck["step"] == 2 and ck["model_type"] == "unet" and ck["metadata_input_length"] == 8 and len(ck["model_state_dict"]) == 138
+    assert all(torch.isfinite(v).all() for v in ck["model_state_dict"].values() if v.is_floating_point())
+    g = torch.Generator().manual_seed(70)
+    x, ts, md = torch.randn(1, 23, 250, 250, generator=g).cuda(), torch.randn(1, 24, generator=g).cuda(), torch.randn(1, 8, generator=g).cuda()
+    trained = res["model"].eval()
+    with torch.no_grad():
+        ref = trained(x, ts, md)
+    loaded = checkpoint.load_model(path, device="cuda", spatial_channels=23, seq_len=CONFIG.dataset.temporal_length)
+    assert isinstance(loaded, mau.UrbanPredictor) and not loaded.training
+    with torch.no_grad():
+        assert torch.equal(loaded(x, ts, md), ref)
+    assert checkpoint.run_inference(loaded, x.cpu(), md.cpu(), ts.cpu()).shape == (1, 2, 250, 250)

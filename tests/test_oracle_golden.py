@@ -226,3 +226,15 @@ def test_g10_unetpp_deep_supervision():
         assert rel_err(sd[k].grad, g) <= 5e-5 or float((sd[k].grad - g).abs().max()) < 1e-7, k
     for k in m["nograd"]:
         assert sd[k].grad is None, k                       # model.final.* is unused under deep supervision
+
+
+def test_g11_temporal_encoder_828():
+    """TemporalEncoder at the reference's real length (828 monthly temperatures): the oracle's explicit LSTM loop against
+    the reference's nn.LSTM on the fixture -- embedding and every parameter gradient (an 828-step fp32 recurrence: 1e-5)."""
+    d = load_npz("g11_temporal_828.npz")
+    sd = {f"model.temporal_encoder.{k}": t(v).requires_grad_(True) for k, v in sub(d, "sd").items()}
+    emb = R.temporal_encoder(t(d["ts"]), sd)
+    assert rel_err(emb, t(d["emb"])) < 1e-5
+    emb.backward(t(d["demb"]))
+    for k, g in sub(d, "grad").items():
+        assert rel_err(sd[f"model.temporal_encoder.{k}"].grad, g) < 1e-4, k
