@@ -114,8 +114,13 @@ __device__ __forceinline__ void dma_issue(const LoaderArgs la, unsigned long lon
   const int c = c0 + slot_c;
   const int add = halo ? ua + slot_c : 0;
   const bool valid = off32 >= 0;
-  const unsigned long long pt = ub + 2ull * ((unsigned long long)(unsigned)off32 * um + (unsigned long long)add);
-  const unsigned long long pe = embn_a + 2ull * (unsigned long long)(long long)(c - la.Ctot);
+  unsigned long long pt = ub + 2ull * ((unsigned long long)(unsigned)off32 * um + (unsigned long long)add);
+  unsigned long long pe = embn_a + 2ull * (unsigned long long)(long long)(c - la.Ctot);
+#ifndef MAU_CONV_BRANCHY_LOADER
+  // both candidates are materialised unconditionally: left to itself the compiler sinks the 64-bit multiply-add into an
+  // exec-masked branch per DMA (s_and_saveexec + s_cbranch_execz in the middle of the MFMA stream)
+  asm volatile("" : "+v"(pt), "+v"(pe));
+#endif
   const bool is_t = valid & (c < ulim);
   const bool is_e = valid & halo & ((unsigned)(c - la.Ctot) < (unsigned)la.E);
   const unsigned long long src = is_t ? pt : (is_e ? pe : la.zero_a);
@@ -271,20 +276,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;   // (bias-initialised accumulators make the MT = 4 variants spill 100 registers)
 
-    // ---- K loop.  Per stage: wait for this wave's DMAs -> raw barrier (every wave's DMAs have landed and
-    // everyone is done with the buffer that is refilled next) -> issue the following stage, which may
-    // already belong to the NEXT work item (cross-tile pipelining) -> multiply. ----
-    for (int chunk = 0; chunk < p.nChunks; ++chunk) {
-      // This wave's DMAs of the stage must have landed.  After an interior item's epilogue the 4 * MT output stores (and
-      // the statistics row) were issued AFTER those DMAs: the vector-memory counter retires in issue order, so waiting
-      // until at most 4 * MT operations are outstanding covers the DMAs without waiting out the stores' HBM write
-      // round trip (with vmcnt(0) every item of a short-K layer paid it: -21 % on the level-0 layers).
+    // ---- K loop.  Between two stages: wait for this wave's DMAs -> raw barrier (every wave's DMAs have landed and
+    // everyone is done with the buffer that is refilled next); inside a stage: issue the following stage, which may
+    // already belong to the NEXT work item (cross-tile pipelining), and multiply. ----
+    // The first stage's wait stands BEFORE the loop: after an interior item's epilogue the 4 * MT output stores (and the
+    // statistics row) were issued AFTER the stage's DMAs; the vector-memory counter retires in issue order, so waiting until
+    // at most 4 * MT operations are outstanding covers the DMAs without waiting out the stores' HBM write round trip
+    // (with vmcnt(0) every item of a short-K layer paid it).  (A flag tested at the loop head made the compiler peel the
+    // first iteration, with register reloads and full vmcnt(0) drains inside the peeled copy.)
 #ifndef MAU_CONV_NO_COUNTED_EPI
-      if (chunk == 0 && stores_behind) wait_vmcnt<4 * MT>();
-      else
+    if (stores_behind) wait_vmcnt<4 * MT>();
+    else
 #endif
-        wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    for (int chunk = 0; chunk < p.nChunks; ++chunk) {
       // next stage: the following chunk of this item, or chunk 0 of the next item (cross-tile pipelining);
       // after the very last stage chunk 0 of the current item is re-fetched into the idle buffer (nobody reads it)
       const bool more = chunk + 1 < p.nChunks;
@@ -319,6 +325,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
       MAU_TAP(0) MAU_TAP(1) MAU_TAP(2) MAU_TAP(3) MAU_TAP(4) MAU_TAP(5) MAU_TAP(6) MAU_TAP(7) MAU_TAP(8)
 #undef MAU_TAP
       stage ^= 1;
+      if (more) {                                      // (after the last stage the epilogue's barrier takes this place)
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+      }
     }
 
     // ---- epilogue of `cur` (the next item's first stage is already in flight into buffer `stage`) ----

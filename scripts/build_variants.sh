@@ -11,7 +11,7 @@ for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
   ( /opt/rocm/bin/hipcc $FLAGS $defs -c $SRC -o ../variants/${SRC%.hip}_$name.o
     objs=""
-    for f in capi conv3x3 conv3x3_bf16 conv3x3_wgrad_bf16 bn spatial head lstm loss; do
+    for f in capi conv3x3 conv3x3_bf16 conv3x3_wgrad_bf16 bn spatial head lstm ssim; do
       [ -f $f.hip ] || continue
       if [ "$f.hip" == "$SRC" ]; then objs="$objs ../variants/${SRC%.hip}_$name.o"; else objs="$objs $f.o"; fi
     done
