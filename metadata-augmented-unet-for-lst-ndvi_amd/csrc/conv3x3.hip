@@ -335,38 +335,49 @@ __device__ __forceinline__ int pack_row_channel(int q) {
   return sizeof(T) == 2 ? (q & ~63) + 2 * (q & 31) + ((q >> 5) & 1) : q;
 }
 
+// One block = one tile of a pack: 64 row positions x one 16-channel K chunk x 9 taps, staged through LDS so that both the
+// fp32 OIHW reads (runs of 144 / 576 contiguous floats) and the packed writes (2 KiB contiguous per tap) are coalesced.
+//   forward tile  (blockIdx.x <  tilesF): rows = 64 output channels, k = 16 input channels, tap t  -> wf[ci/16][t][co'][ci%16]
+//   dgrad tile    (blockIdx.x >= tilesF): rows = 64 input channels,  k = 16 output channels, tap t -> wd[co/16][8-t][ci'][co%16]
+// (an element-per-thread gather ran at ~1 TB/s: 0.22 ms per training step for the U-Net's 18 layers)
 template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
-                                    int Cout, int Cin) {
-  constexpr int KC = PackKC<T>::value;
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
+                                                           int Cout, int Cin, int tilesF) {
+  constexpr int KC = PackKC<T>::value;                 // 16
+  __shared__ float tile[64][KC * 9 + 1];
   const int CoutPad = (Cout + 63) / 64 * 64, CinPad = (Cin + 63) / 64 * 64;
-  const int nChF = (Cin + KC - 1) / KC, nChD = (Cout + KC - 1) / KC;
-  const size_t nF = wf ? (size_t)nChF * 9 * CoutPad * KC : 0, nD = (size_t)nChD * 9 * CinPad * KC;
-  const size_t total = nF + (wd ? nD : 0);
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    if (idx < nF) {
-      size_t t = idx;
-      const int kc = t % KC;
-      t /= KC;
-      const int co = pack_row_channel<T>((int)(t % CoutPad));
-      t /= CoutPad;
-      const int tap = t % 9;
-      const int ci = (int)(t / 9) * KC + kc;
-      float v = 0.f;
-      if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 9 + tap];
-      wf[idx] = (T)v;
-    } else {
-      size_t t = idx - nF;
-      const int kc = t % KC;
-      t /= KC;
-      const int ci = pack_row_channel<T>((int)(t % CinPad));
-      t /= CinPad;
-      const int tap = t % 9;
-      const int co = (int)(t / 9) * KC + kc;
-      float v = 0.f;
-      if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];
-      wd[idx - nF] = (T)v;
+  const bool fwd = (int)blockIdx.x < tilesF;
+  const int t = fwd ? blockIdx.x : blockIdx.x - tilesF;
+  const int rowBlocks = (fwd ? CoutPad : CinPad) / 64;
+  const int rb = t % rowBlocks, chunk = t / rowBlocks;
+  const int nRow = fwd ? Cout : Cin, nK = fwd ? Cin : Cout;
+  // ---- load: tile[r][k*9 + tap] ----
+  if (fwd) {
+    for (int e = threadIdx.x; e < 64 * KC * 9; e += 256) {
+      const int r = e / (KC * 9), kt = e % (KC * 9);
+      const int co = rb * 64 + r, ci = chunk * KC + kt / 9;
+      tile[r][kt] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + chunk * KC) * 9 + kt] : 0.f;
     }
+  } else {
+    for (int e = threadIdx.x; e < KC * 64 * 9; e += 256) {
+      const int k = e / (64 * 9), rt = e % (64 * 9);
+      const int r = rt / 9, tap = rt % 9;
+      const int co = chunk * KC + k, ci = rb * 64 + r;
+      tile[r][k * 9 + tap] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + rb * 64) * 9 + rt] : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- store: out[((chunk*9 + tapOut) * RowPad + rb*64 + pos) * KC + k], 8 elements (k .. k+7) per thread and step ----
+  T* out = fwd ? wf : wd;
+  const int RowPad = fwd ? CoutPad : CinPad;
+  for (int e = threadIdx.x; e < 9 * 64 * (KC / 8); e += 256) {
+    const int k8 = e % (KC / 8), pos = (e / (KC / 8)) % 64, tap = e / (64 * (KC / 8));
+    const int r = sizeof(T) == 2 ? 2 * (pos & 31) + (pos >> 5) : pos;          // channel held by position pos (pack_row_channel)
+    const int tapOut = fwd ? tap : 8 - tap;
+    F8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] = tile[r][(k8 * 8 + j) * 9 + tap];
+    store8<T>(out + (((size_t)chunk * 9 + tapOut) * RowPad + rb * 64 + pos) * KC + k8 * 8, v);
   }
 }
 
@@ -473,9 +484,10 @@ int mau_conv3x3_pack_weights(const float* w, void* wf, void* wd, int dtype, int 
                              mau_stream_t stream) {
   MAU_REQUIRE(w && (wf || wd) && Cout > 0 && Cin > 0, "pack_weights: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  const size_t total = (wf ? mau_conv3x3_packed_elems(dtype, Cout, Cin) : 0) + (wd ? mau_conv3x3_packed_elems(dtype, Cin, Cout) : 0);
-  const int grid = stream_grid((int64_t)total, 256);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(pack_weights_kernel<T>, dim3(grid), dim3(256), 0, st, w, (T*)wf, (T*)wd, Cout, Cin));
+  const int kc = mau_conv3x3_kc(dtype);
+  const int tilesF = wf ? (round_up(Cout, 64) / 64) * ceil_div(Cin, kc) : 0;
+  const int tilesD = wd ? (round_up(Cin, 64) / 64) * ceil_div(Cout, kc) : 0;
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(pack_weights_kernel<T>, dim3(tilesF + tilesD), dim3(256), 0, st, w, (T*)wf, (T*)wd, Cout, Cin, tilesF));
   return check_launch("pack_weights_kernel");
 }
 

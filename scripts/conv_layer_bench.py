@@ -25,6 +25,7 @@ def timeit(fn, reps=8):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}; totf = 0.0
+records = []
 print(f"{'layer':16s} {'Cin':>5s} {'Cout':>5s} {'H':>4s} {'GFLOP':>8s} | {'fwd us':>8s} {'TF/s':>6s} | {'dgrad us':>8s} {'TF/s':>6s} | {'wgrad us':>8s} {'TF/s':>6s} | {'HBM floor us':>11s}")
 for name, cin, cout, h in layers:
     N, H, W = B, h, h
@@ -48,4 +49,21 @@ for name, cin, cout, h in layers:
     floor = (F_.pad8(cin) + F_.pad8(cout)) * N * H * W * 2 / 5.5e12
     print(f"{name:16s} {cin:5d} {cout:5d} {h:4d} {fl/1e9:8.1f} | {tf*1e6:8.1f} {fl/tf/1e12:6.0f} | {td*1e6:8.1f} {fl/td/1e12:6.0f} | {tw*1e6:8.1f} {fl/tw/1e12:6.0f} (s={ns:3d}) | {floor*1e6:11.1f}")
     tot["fwd"] += tf; tot["dgrad"] += td if name != "conv0_0.conv1" else 0; tot["wgrad"] += tw; totf += fl
+    minb = (F_.pad8(cin) + F_.pad8(cout)) * N * H * W * 2 + 9 * cin * cout * 2
+    records.append({"layer": name, "Cin": cin, "Cout": cout, "H": h, "B": B, "gflop": fl / 1e9, "min_hbm_bytes": minb,
+                    "variant": ("BN128" if ((cout + 63) // 64 * 64) % 128 == 0 else "BN64") + f"/tiles{tiles}",
+                    **{k: {"us": t * 1e6, "tflops": fl / t / 1e12, "tbps_min_bytes": minb / t / 1e12} for k, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw))},
+                    "wgrad_splits": ns})
 print(f"TOTAL fwd {tot['fwd']*1e3:.2f} ms ({totf/tot['fwd']/1e12:.0f} TF/s)  dgrad {tot['dgrad']*1e3:.2f} ms  wgrad {tot['wgrad']*1e3:.2f} ms ({totf/tot['wgrad']/1e12:.0f} TF/s)")
+
+if os.environ.get("OUT"):
+    import json
+    d00 = [r for r in records if r["layer"].startswith("conv0_0")]
+    json.dump({"what": "per-layer timing of the three convolution kernels through the C ABI, events on the launch stream, 8 launches each after 2 warm-ups "
+                       "(scripts/conv_layer_bench.py); bf16, B=%d, %dx%d input" % (B, S, S),
+               "peaks": {"bf16_mfma_tflops": 2500.0, "hbm_tbps": 8.0, "hbm_achievable_tbps": 6.3},
+               "north_star_layer_conv0_0_DoubleConv": {"fwd_us": sum(r["fwd"]["us"] for r in d00), "gflop": sum(r["gflop"] for r in d00),
+                                                      "min_hbm_bytes": sum(r["min_hbm_bytes"] for r in d00),
+                                                      "fwd_tflops": sum(r["gflop"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e-3,
+                                                      "fwd_tbps_min_bytes": sum(r["min_hbm_bytes"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e-6},
+               "totals_ms": {k: v * 1e3 for k, v in tot.items()}, "layers": records}, open(os.environ["OUT"], "w"), indent=1)

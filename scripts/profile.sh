@@ -1,14 +1,15 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun):
-#   scripts/profile.sh <tag>      -> gpurun_out/prof_<tag>/{stats,pmc_*}/...
+# Collect the rocprofv3 evidence of one bench workload on the GPU box (run through gpurun):
+#   scripts/profile.sh <tag> [bench.py arguments ...]     -> gpurun_out/prof_<tag>/{stats,pmc_*}/...
 # kernel-trace/--stats and every --pmc set run as SEPARATE passes (gpurun refuses --pmc together
 # with sys/hip/hsa tracing, and FETCH_SIZE / WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md).
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}; shift || true
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+echo "$BENCH" > "$OUT/command.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
 echo "stats pass rc=$?"
 i=0
@@ -17,4 +18,3 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/pmc_$i" -- $BENCH > "$OUT/pmc_$i.log" 2>&1
   echo "pmc pass $i ($PMC) rc=$?"
 done
-ls -R "$OUT" | head -40

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Turn the raw rocprofv3 output of scripts/profile.sh (gpurun_out/prof_<tag>/) into the committed summaries:
-   profiles/<round>/kernel_stats_bench_steps3.csv, pmc_per_kernel.csv, dominant_kernel_summary.json
-Usage: scripts/summarize_profile.py gpurun_out/prof_<tag> profiles/r1"""
+   profiles/<round>/<key>/kernel_stats_bench_steps3.csv, pmc_per_kernel.csv, dominant_kernel_summary.json
+   and the entry <key> of profiles/<round>/pmc_summary.json that bench.py reads (roofline.traffic / mfma_busy).
+Usage: scripts/summarize_profile.py gpurun_out/prof_<tag> profiles/r2 <workload key as bench.py's workload_key()>"""
 import collections, csv, glob, json, os, shutil, sys
 
-src, dst = sys.argv[1], sys.argv[2]
+src, root, key = sys.argv[1], sys.argv[2], sys.argv[3]
+dst = os.path.join(root, key)
 os.makedirs(dst, exist_ok=True)
 stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
 shutil.copy(stats, os.path.join(dst, "kernel_stats_bench_steps3.csv"))
@@ -50,14 +52,23 @@ def family(pred):
     return out
 
 
+cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 summary = {
-    "command": "rocprofv3 --kernel-trace [--stats | --pmc <set>] --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   (4 train steps + 7 eval forwards; scripts/profile.sh, scripts/summarize_profile.py)",
+    "command": f"rocprofv3 --kernel-trace [--stats | --pmc <set>] --output-format csv -- {cmd}   (4 timed-region steps + 7 eval forwards; scripts/profile.sh, scripts/summarize_profile.py)",
     "correction": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced reads incl. LDS-DMA; WRITE_SIZE is exact for 16-B stores (MI355X_MICROARCH.md, HBM section)",
     "mfma_busy_fraction": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs)",
     "conv3x3_bf16_kernel (dominant: forward + data gradient)": family(lambda n: "conv3x3_bf16_kernel" in n),
     "wgrad_bf16_kernel": family(lambda n: "wgrad_bf16_kernel" in n),
 }
 json.dump(summary, open(os.path.join(dst, "dominant_kernel_summary.json"), "w"), indent=1)
+dom = summary["conv3x3_bf16_kernel (dominant: forward + data gradient)"]
+pj = os.path.join(root, "pmc_summary.json")
+allk = json.load(open(pj)) if os.path.exists(pj) else {}
+allk[key] = {"hbm_bytes_per_launch": dom.get("hbm_bytes_per_launch_pmc"), "mfma_busy": dom.get("mfma_busy_fraction"),
+             "avg_launch_us_rocprof": dom["avg_launch_us_rocprof"], "launches": dom["launches"], "l2_hit_rate": dom.get("l2_hit_rate"),
+             "lds_bank_conflict_fraction": dom.get("lds_bank_conflict_fraction"), "command": cmd,
+             "wgrad": summary["wgrad_bf16_kernel"]}
+json.dump(allk, open(pj, "w"), indent=1)
 print(json.dumps(summary, indent=1))
 top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:12]
 for r in top:
