@@ -191,6 +191,7 @@ class BNState:
     frozen: object = None                 # dict of a frozen inference session (packed weights, scale, shift) or None
     C1: int = 0                           # logical channels of the second tensor source (virtual concat), 0 = none
     pool: bool = False                    # also return maxpool2x2(output) (encoder blocks: skip + next level)
+    out_view: object = None               # preallocated NHWC-ld view the activation is written into (U-Net++ row buffers)
 
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
@@ -246,12 +247,15 @@ class ConvBNReLU(torch.autograd.Function):
         needs = ctx.needs_input_grad
         inference = (not st.training) and (not st.grad_enabled or not any(needs))
         emb_ws = torch.empty((N, E), dtype=x.dtype, device=dev) if E else None
-        y = torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
+        dst = st.out_view                               # where the activation goes: a slot of a row buffer, or a fresh tensor
+        if dst is not None and (tuple(dst.shape) != (N, H, W, ldy) or dst.dtype != x.dtype or Cout % 64 != 0):
+            raise RuntimeError("conv3x3: out_view must be an (N,H,W,Cout) NHWC-ld view of the activation dtype with Cout % 64 == 0")
+        y = dst if (inference and dst is not None) else torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
 
         def pooled_of(a):
             pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
-            call("mau_maxpool2x2_fwd", a.data_ptr(), ldy, pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
+            call("mau_maxpool2x2_fwd", a.data_ptr(), _ld(a), pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
             return pl
 
         if inference:
@@ -306,14 +310,15 @@ class ConvBNReLU(torch.autograd.Function):
             call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                  st.eps, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cout, stream)
             _conv_fwd(x, x1, st, emb, emb_ws, E, wf, bias, None, y, Cout, None, code, N, H, W, stream)
-        a = torch.empty_like(y)
+        a = dst if dst is not None else torch.empty_like(y)
+        lda = _ld(a)
         pl = None
         if st.pool and H >= 2 and W >= 2:
             pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
-            call("mau_bn_relu_apply_pool", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), ldy,
+            call("mau_bn_relu_apply_pool", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), lda,
                  pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
         else:
-            call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), ldy, code,
+            call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), lda, code,
                  npix, Cout, stream)
         ctx.st = st
         ctx.E = E
@@ -343,10 +348,10 @@ class ConvBNReLU(torch.autograd.Function):
             dpl = _as_nhwc(dpl)
             dsum = torch.empty((N, H, W, ldy), dtype=y.dtype, device=dev)
             if da is None:
-                call("mau_maxpool2x2_bwd", a.data_ptr(), ldy, dpl.data_ptr(), _ld(dpl), dsum.data_ptr(), ldy, code, N, H, W, Cout, stream)
+                call("mau_maxpool2x2_bwd", a.data_ptr(), _ld(a), dpl.data_ptr(), _ld(dpl), dsum.data_ptr(), ldy, code, N, H, W, Cout, stream)
             else:
                 da = _as_nhwc(da)
-                call("mau_maxpool2x2_bwd_add", a.data_ptr(), ldy, dpl.data_ptr(), _ld(dpl), da.data_ptr(), _ld(da),
+                call("mau_maxpool2x2_bwd_add", a.data_ptr(), _ld(a), dpl.data_ptr(), _ld(dpl), da.data_ptr(), _ld(da),
                      dsum.data_ptr(), ldy, code, N, H, W, Cout, stream)
             da = dsum
         elif da is None:
@@ -498,6 +503,28 @@ def _resize_into(src, Cs, h, w, dst, choff, N, H, W, code, stream):
         tmp = torch.empty((N, H, W, pad8(Cs)), dtype=dst.dtype, device=dst.device)
         call("mau_resize_bilinear_fwd", src.data_ptr(), _ld(src), h, w, tmp.data_ptr(), pad8(Cs), 0, code, N, H, W, Cs, stream)
         call("mau_copy_channels", tmp.data_ptr(), pad8(Cs), dst.data_ptr(), _ld(dst), choff, 0, code, N * H * W, Cs, stream)
+
+
+class RowPrefix(torch.autograd.Function):
+    """torch.cat([x_0, ..., x_{k-1}], 1) for activations that ALREADY sit side by side in one row buffer (U-Net++: the
+    nodes x^{i,0..j-1} of a row are the leading inputs of node x^{i,j}, src/model.py:136-177): the result is a view of the
+    buffer -- no copy -- and the backward hands every input its channel slice of the gradient, also as views."""
+
+    @staticmethod
+    def forward(ctx, C, *xs):
+        base = xs[0]
+        ld, esz = base.stride(2), base.element_size()
+        for j, t in enumerate(xs):
+            if t.data_ptr() != base.data_ptr() + j * C * esz or t.stride() != base.stride() or t.shape != base.shape:
+                raise RuntimeError("RowPrefix: inputs are not adjacent channel slots of one row buffer")
+        N, H, W, _ = base.shape
+        ctx.C, ctx.k = C, len(xs)
+        return base.as_strided((N, H, W, C * len(xs)), base.stride())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _as_nhwc(g)
+        return (None, *[g[..., j * ctx.C:(j + 1) * ctx.C] for j in range(ctx.k)])
 
 
 class UpsampleTo(torch.autograd.Function):

@@ -75,23 +75,24 @@ class VGGBlock(nn.Module):
         if self._frozen is not None:
             self._frozen = [{}, {}]
 
-    def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d, x1: Optional[Act] = None, pool: bool = False):
+    def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d, x1: Optional[Act] = None, pool: bool = False, out_view=None):
         rt = self._rt or _Runtime()
         st = BNState(training=self.training and bn.training, C0=x.C, momentum=bn.momentum, eps=bn.eps,
                      group=rt.group, world=rt.world, grad_enabled=torch.is_grad_enabled(),
                      frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1],
-                     C1=0 if x1 is None else x1.C, pool=pool)
+                     C1=0 if x1 is None else x1.C, pool=pool, out_view=out_view)
         t = F_.ConvBNReLU.apply(x.t, None if x1 is None else x1.t, emb, conv.weight, conv.bias, bn.weight, bn.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, st)
         if pool:
             return Act(t[0], conv.out_channels), Act(t[1], conv.out_channels)
         return Act(t, conv.out_channels)
 
-    def forward(self, x: Act, emb: Optional[torch.Tensor] = None, x1: Optional[Act] = None, pool: bool = False):
+    def forward(self, x: Act, emb: Optional[torch.Tensor] = None, x1: Optional[Act] = None, pool: bool = False, out_view=None):
         """``x1``: second input tensor, channel-concatenated after ``x`` by the conv loader (never materialised);
-        ``pool=True`` returns ``(block output, maxpool2x2(block output))``."""
+        ``pool=True`` returns ``(block output, maxpool2x2(block output))``; ``out_view``: preallocated NHWC view the block's
+        output is written into (a slot of a U-Net++ row buffer)."""
         x = self._half(x, emb, self.conv1, self.bn1, x1)
-        return self._half(x, None, self.conv2, self.bn2, None, pool)
+        return self._half(x, None, self.conv2, self.bn2, None, pool, out_view)
 
 
 class TemporalEncoder(nn.Module):
@@ -181,10 +182,10 @@ class _NetBase(nn.Module):
             return maps
         return Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
 
-    def _block_pool(self, block: VGGBlock, x: Act):
+    def _block_pool(self, block: VGGBlock, x: Act, out_view=None):
         """(pool(block(x)), block(x)): the encoder block's second BatchNorm+ReLU pass also writes the pooled tensor, and
         its backward adds the pool's and the skip connection's gradients in one pass."""
-        a, p = block(x, pool=True)
+        a, p = block(x, pool=True, out_view=out_view)
         return p, a
 
     def _fusable(self, skip: Act) -> bool:
@@ -338,38 +339,62 @@ class UrbanPredictor_unetpp(_NetBase):
             self.final = nn.Conv2d(nb[0], out_channels, kernel_size=1)
         self._bind_runtime()
 
-    def _node(self, block: VGGBlock, skips: List[Act], below: Act, emb: torch.Tensor) -> Act:
+    def _node(self, block: VGGBlock, skips: List[Act], below: Act, emb: torch.Tensor, out_view=None) -> Act:
         # cat([skips..., _upsample_match(below, (H, W)), emb_map], 1), src/model.py:111-121,136-177
         fused_emb = (sum(s.C for s in skips) + below.C) % 8 == 0 and emb.shape[1] % 8 == 0
-        if len(skips) == 1 and fused_emb and self._fusable(skips[0]):
+        rows = out_view is not None or getattr(self, "_rows_active", False)
+        if fused_emb and self._fusable(skips[0]) and (len(skips) == 1 or rows):
+            # [skips | up | broadcast(emb)] are three sources of the conv loader; with row buffers the skips of a row
+            # already sit side by side (RowPrefix: a view, no copy)
+            first = skips[0] if len(skips) == 1 else Act(F_.RowPrefix.apply(skips[0].C, *[s.t for s in skips]), sum(s.C for s in skips))
             up = Act(F_.UpsampleTo.apply(below.t, below.C, False, skips[0].H, skips[0].W), below.C)
-            return block(skips[0], emb, up)           # [skip, up, broadcast(emb)]: three sources of the conv loader
+            return block(first, emb, up, out_view=out_view)
         t = F_.ConcatUp.apply(below.t, below.C, False, tuple(s.C for s in skips), *[s.t for s in skips])
         x = Act(t, sum(s.C for s in skips) + below.C)
         if x.C % 8 == 0 and emb.shape[1] % 8 == 0:
-            return block(x, emb)                      # broadcast embedding folded into the conv loader
-        return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]))
+            return block(x, emb, out_view=out_view)       # broadcast embedding folded into the conv loader
+        return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]), out_view=out_view)
 
     def forward(self, maps, temp_series, metadata):
         temporal_emb = self.temporal_encoder(temp_series)
         meta_emb = self.meta_encoder(metadata)
         emb = torch.cat([temporal_emb, meta_emb], dim=1).float()           # src/model.py:103
         x = self._entry(maps)
-        p, x0_0 = self._block_pool(self.conv0_0, x)         # (the skip feeds every node of the row)
-        p, x1_0 = self._block_pool(self.conv1_0, p)
-        x0_1 = self._node(self.conv0_1, [x0_0], x1_0, emb)
-        p, x2_0 = self._block_pool(self.conv2_0, p)
-        x1_1 = self._node(self.conv1_1, [x1_0], x2_0, emb)
-        x0_2 = self._node(self.conv0_2, [x0_0, x0_1], x1_1, emb)
+        # Row buffers: the nodes x^{i,0..} of one resolution are written side by side into one (N,H,W,slots*C) buffer, so
+        # that "cat of the earlier nodes of the row" is a view.  Needs 64-channel-aligned blocks and a 16-bit dtype.
+        nb0 = self.conv0_0.conv2.out_channels
+        use_rows = self._rt.dtype != torch.float32 and nb0 % 64 == 0 and os.environ.get("MAU_VIRTUAL_CONCAT", "1") != "0"
+        self._rows_active = use_rows
+        N, H, W = x.t.shape[0], x.t.shape[1], x.t.shape[2]
+        hs, ws = [H], [W]
+        for _ in range(3):
+            hs.append(hs[-1] // 2)
+            ws.append(ws[-1] // 2)
+
+        def row_hw(level, slots):
+            if not use_rows:
+                return [None] * slots
+            C = nb0 << level
+            buf = torch.empty((N, hs[level], ws[level], slots * C), dtype=self._rt.dtype, device=x.t.device)
+            return [buf[..., j * C:(j + 1) * C] for j in range(slots)]
+
+        r0, r1, r2 = row_hw(0, 4), row_hw(1, 3), row_hw(2, 2)
+        p, x0_0 = self._block_pool(self.conv0_0, x, r0[0])         # (the skip feeds every node of the row)
+        p, x1_0 = self._block_pool(self.conv1_0, p, r1[0])
+        x0_1 = self._node(self.conv0_1, [x0_0], x1_0, emb, r0[1])
+        p, x2_0 = self._block_pool(self.conv2_0, p, r2[0])
+        x1_1 = self._node(self.conv1_1, [x1_0], x2_0, emb, r1[1])
+        x0_2 = self._node(self.conv0_2, [x0_0, x0_1], x1_1, emb, r0[2])
         p, x3_0 = self._block_pool(self.conv3_0, p)
-        x2_1 = self._node(self.conv2_1, [x2_0], x3_0, emb)
-        x1_2 = self._node(self.conv1_2, [x1_0, x1_1], x2_1, emb)
-        x0_3 = self._node(self.conv0_3, [x0_0, x0_1, x0_2], x1_2, emb)
+        x2_1 = self._node(self.conv2_1, [x2_0], x3_0, emb, r2[1])
+        x1_2 = self._node(self.conv1_2, [x1_0, x1_1], x2_1, emb, r1[2])
+        x0_3 = self._node(self.conv0_3, [x0_0, x0_1, x0_2], x1_2, emb, r0[3])
         x4_0 = self.conv4_0(p)
         x3_1 = self._node(self.conv3_1, [x3_0], x4_0, emb)
         x2_2 = self._node(self.conv2_2, [x2_0, x2_1], x3_1, emb)
         x1_3 = self._node(self.conv1_3, [x1_0, x1_1, x1_2], x2_2, emb)
         x0_4 = self._node(self.conv0_4, [x0_0, x0_1, x0_2, x0_3], x1_3, emb)
+        self._rows_active = False
         if self.deep_supervision:
             return [F_.Head.apply(a.t, a.C, f.weight, f.bias, False)          # bare 1x1 convs, no tanh (src/model.py:180-185)
                     for a, f in ((x0_1, self.final1), (x0_2, self.final2), (x0_3, self.final3), (x0_4, self.final4))]

@@ -304,11 +304,13 @@ def test_frozen_inference_matches_and_unfreezes(mau):
     assert blk._frozen is None
 
 
-@pytest.mark.parametrize("model_type", ["unet", "unet++"])
-def test_virtual_concat_and_fused_pool_are_bitwise_equal_to_materialised(mau, model_type, monkeypatch):
+@pytest.mark.parametrize("model_type,base", [("unet", 16), ("unet++", 16), ("unet++", 64)])
+def test_virtual_concat_and_fused_pool_are_bitwise_equal_to_materialised(mau, model_type, base, monkeypatch):
     """The decoder's torch.cat([skip, up], 1) (src/model.py:279-282) read by the conv loader from two tensors must give,
     bit for bit, the results of the materialised concat buffer (same K order, same arithmetic): outputs, loss and every
-    gradient of one bf16 training step at base_filters=16 (all channel counts on 16-channel stage boundaries)."""
+    gradient of one bf16 training step at base_filters=16 (all channel counts on 16-channel stage boundaries).  U-Net++ at
+    base_filters=64 additionally runs on ROW BUFFERS (the nodes of a row written side by side, "cat of the earlier nodes"
+    a view: functional.RowPrefix) -- same bitwise requirement, plus an eval forward."""
     flags = {} if model_type == "unet++" else dict(temporal_embeddings=False, metadata_embeddings=True)
     g = torch.Generator().manual_seed(31)
     x, ts, md = torch.randn(2, 6, 48, 40, generator=g).cuda(), torch.randn(2, 10, generator=g).cuda(), torch.randn(2, 4, generator=g).cuda()
@@ -317,12 +319,15 @@ def test_virtual_concat_and_fused_pool_are_bitwise_equal_to_materialised(mau, mo
     for virt in ("1", "0"):
         monkeypatch.setenv("MAU_VIRTUAL_CONCAT", virt)
         torch.manual_seed(30)
-        net = mau.UrbanPredictor(model_type, 6, 10, 16, 4, 16, 24, 2, base_filters=16, **flags).cuda().set_precision("bf16").train()
+        net = mau.UrbanPredictor(model_type, 6, 10, 16, 4, 16, 24, 2, base_filters=base, **flags).cuda().set_precision("bf16").train()
         out = net(x, ts, md)
         loss = mau.compute_loss_mse(out, tgt)["total"]
         loss.backward()
-        res.append((out.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        net.eval()
+        with torch.no_grad():
+            ev = net(x, ts, md)
+        res.append((out.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, ev))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3])
     assert res[0][2].keys() == res[1][2].keys()
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
