@@ -64,6 +64,6 @@ if os.environ.get("OUT"):
                "peaks": {"bf16_mfma_tflops": 2500.0, "hbm_tbps": 8.0, "hbm_achievable_tbps": 6.3},
                "north_star_layer_conv0_0_DoubleConv": {"fwd_us": sum(r["fwd"]["us"] for r in d00), "gflop": sum(r["gflop"] for r in d00),
                                                       "min_hbm_bytes": sum(r["min_hbm_bytes"] for r in d00),
-                                                      "fwd_tflops": sum(r["gflop"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e-3,
+                                                      "fwd_tflops": sum(r["gflop"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e3,
                                                       "fwd_tbps_min_bytes": sum(r["min_hbm_bytes"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e-6},
                "totals_ms": {k: v * 1e3 for k, v in tot.items()}, "layers": records}, open(os.environ["OUT"], "w"), indent=1)
