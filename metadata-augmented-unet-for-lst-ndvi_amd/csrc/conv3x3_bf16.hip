@@ -72,7 +72,7 @@ struct Item {
 // Geometry of a variant: NW waves = WM (pixel direction) x WN (= BN/64 channel direction); a wave owns
 // MT x 32 pixels (MT x 2 tile rows of 16) x 64 channels = MT x 2 accumulator tiles of 32x32.
 //   <128, 2, 8>: 16x16 px tile     <128, 4, 8>: 32x16 px tile (128 accumulator registers per lane)
-//   < 64, 2, 4>: 16x16             < 64, 2, 8>: 32x16
+//   < 64, 2, 4>: 16x16             < 64, 2, 8>: 32x16             < 64, 4, 8>: 64x16 px tile (128 accumulator registers)
 // Larger tiles move fewer LDS-DMA bytes per MFMA (weights are shared by more pixels, the halo by more
 // channels): the ablation in DESIGN.md prices each DMA stream at ~12 % of the kernel time.
 template <int BN, int MT, int NW>
@@ -466,18 +466,19 @@ static int launch(const ConvP& p, hipStream_t st) {
 // +5..9 % on full grids), but quarter the number of work items: a layer whose items do not fill the 256 CUs (or that
 // wastes tile rows on a small image) is better off with 16-row tiles.  Score = grid-fill x tile-fill x variant bonus.
 static inline int tile_height(int CoutPad, int N, int H, int W) {
-  static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 32;
+  static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 64;
   const bool wide = CoutPad % 128 == 0;
   const int nCt = CoutPad / (wide ? 128 : 64);
   int best = 16;
   double best_score = -1.0;
-  for (int th = 16; th <= 32 && th <= th_max; th *= 2) {
+  // 64-row tiles exist for the 64-wide variant only (<64,4,8>: the per-MFMA LDS-read and DMA ratios of <128,4,8>)
+  for (int th = 16; th <= (wide ? 32 : 64) && th <= th_max; th *= 2) {
     const int slots = 256 * ((!wide && th == 16) ? 2 : 1);         // <64,2,4> runs two workgroups per CU
     const long tilesY = ceil_div(H, th), tilesX = ceil_div(W, TW);
     const long items = (long)N * tilesY * tilesX * nCt;
     const double grid_fill = (double)items / (double)(((items + slots - 1) / slots) * slots);
     const double tile_fill = (double)H * W / (double)(tilesY * th * tilesX * TW);
-    const double score = grid_fill * tile_fill * (th == 32 ? 1.06 : 1.0);
+    const double score = grid_fill * tile_fill * (th == 64 ? 1.10 : th == 32 ? 1.06 : 1.0);
     if (score > best_score) {
       best_score = score;
       best = th;
@@ -491,7 +492,8 @@ static inline int tile_height(int CoutPad, int N, int H, int W) {
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   const int CoutPad = round_up(Cout, 64);
   const int th = v2::tile_height(CoutPad, N, H, W);
-  const int wm = (CoutPad % 128 != 0 && th == 32) ? v2::Geo<64, 2, 8>::WM : 4;     // <128,2,8>, <128,4,8>, <64,2,4>: WM = 4
+  const int wm = (CoutPad % 128 != 0 && th >= 32) ? v2::Geo<64, 2, 8>::WM : 4;     // <128,2,8>, <128,4,8>, <64,2,4>: WM = 4; <64,2,8>, <64,4,8>: 8
+  static_assert(v2::Geo<64, 2, 8>::WM == 8 && v2::Geo<64, 4, 8>::WM == 8 && v2::Geo<64, 4, 8>::TH == 64, "slab rows");
   static_assert(v2::Geo<128, 2, 8>::WM == 4 && v2::Geo<128, 4, 8>::WM == 4 && v2::Geo<64, 2, 4>::WM == 4, "slab rows");
   return wm * N * ceil_div(H, th) * ceil_div(W, v2::TW);
 }
@@ -514,6 +516,7 @@ int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
   }
   const int th = v2::tile_height(p.CoutPad, p.N, p.H, p.W);
   if (p.CoutPad % 128 == 0) return th == 32 ? launch_epi<128, 4, 8>(p, f16, st) : launch_epi<128, 2, 8>(p, f16, st);
+  if (th == 64) return launch_epi<64, 4, 8>(p, f16, st);
   return th == 32 ? launch_epi<64, 2, 8>(p, f16, st) : launch_epi<64, 2, 4>(p, f16, st);
 }
 
