@@ -232,6 +232,73 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
   store8<T>(dsrc + (((size_t)n * h + yi) * w + xi) * lddsrc + c, acc);
 }
 
+// ---- adjoint of an upsampling (scale <= 1 in both directions: every decoder resize of the models) ----------------------
+// (A forward kernel with a 2x2 block of destination pixels per thread -- 9 loads for 4 outputs instead of 16 -- measured
+//  7 % SLOWER than resize_fwd_kernel: the forward is bound by its 4x larger write stream, not by its loads.)
+// Backward: one thread = a 2x2 block of SOURCE pixels x 8 channels; every destination pixel of the union window is loaded
+// once and feeds up to four accumulators (9 loads per output instead of 16 at scale 1/2); per source pixel the
+// accumulation order (destination rows, then columns) and the weights are those of resize_bwd_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd2_kernel(const T* __restrict__ ddst, int ldddst, int choff, int H, int W,
+                                                          T* __restrict__ dsrc, int lddsrc, int h, int w, int C8) {
+  const int nv = C8 >> 3, wc = (w + 1) >> 1;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= wc * nv) return;
+  const int xb = idx / nv, c = (idx - xb * nv) * 8;
+  const int yi0 = 2 * blockIdx.y, xi0 = 2 * xb, n = blockIdx.z;
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  int ja = 0, jb = H - 1, ka = 0, kb = W - 1;
+  if (sy > 0.f) {
+    ja = max(0, (int)floorf(((float)yi0 - 1.f) / sy) - 1);
+    jb = min(H - 1, (int)ceilf(((float)yi0 + 2.f) / sy) + 1);
+  }
+  if (sx > 0.f) {
+    ka = max(0, (int)floorf(((float)xi0 - 1.f) / sx) - 1);
+    kb = min(W - 1, (int)ceilf(((float)xi0 + 2.f) / sx) + 1);
+  }
+  F8 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq) acc[a][bq] = zero8();
+  for (int j = ja; j <= jb; ++j) {
+    int y0, y1;
+    float ly0, ly1;
+    ac_src(sy, j, h, y0, y1, ly0, ly1);
+    float wy[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) wy[a] = (y0 == yi0 + a ? ly0 : 0.f) + (y1 == yi0 + a ? ly1 : 0.f);
+    const bool hit_y0 = (y0 == yi0) | (y1 == yi0), hit_y1 = (y0 == yi0 + 1) | (y1 == yi0 + 1);
+    if (!(hit_y0 | hit_y1)) continue;
+    for (int k = ka; k <= kb; ++k) {
+      int x0, x1;
+      float lx0, lx1;
+      ac_src(sx, k, w, x0, x1, lx0, lx1);
+      float wx[2];
+#pragma unroll
+      for (int bq = 0; bq < 2; ++bq) wx[bq] = (x0 == xi0 + bq ? lx0 : 0.f) + (x1 == xi0 + bq ? lx1 : 0.f);
+      const bool hit_x0 = (x0 == xi0) | (x1 == xi0), hit_x1 = (x0 == xi0 + 1) | (x1 == xi0 + 1);
+      if (!(hit_x0 | hit_x1)) continue;
+      const F8 g = load8<T>(ddst + (((size_t)n * H + j) * W + k) * ldddst + choff + c);
+      const bool hy[2] = {hit_y0, hit_y1}, hx[2] = {hit_x0, hit_x1};
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq)
+          if (hy[a] & hx[bq]) {
+            const float wgt = wy[a] * wx[bq];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[a][bq].v[q] = fmaf(wgt, g.v[q], acc[a][bq].v[q]);
+          }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+      if (yi0 + a < h && xi0 + bq < w) store8<T>(dsrc + (((size_t)n * h + yi0 + a) * w + xi0 + bq) * lddsrc + c, acc[a][bq]);
+}
+
 // dst[..., choff + c] = src[..., c] for c < C (element granularity: tolerates any C / choff), then
 // zero-fill dst channels [choff + C, zero_to)
 template <typename T>
@@ -443,6 +510,11 @@ int mau_resize_bilinear_bwd(const void* ddst, int ldddst, int choff, int H, int 
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldddst % 8 == 0 && lddsrc % 8 == 0 && choff % 8 == 0 && lddsrc >= C8 && ldddst >= choff + C8, "resize_bilinear_bwd: bad ld/choff");
   MAU_REQUIRE(h <= 65535 && N <= 65535, "resize_bilinear_bwd: h and N must fit a grid dimension");
+  if (h <= H && w <= W && h >= 2 && w >= 2) {          // adjoint of an upsampling: 2x2 source pixels per thread
+    dim3 grid2(ceil_div(((w + 1) / 2) * (C8 / 8), 256), (h + 1) / 2, N);
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_bwd2_kernel<T>, grid2, dim3(256), 0, (hipStream_t)stream, (const T*)ddst, ldddst, choff, H, W, (T*)dsrc, lddsrc, h, w, C8));
+    return check_launch("resize_bwd2_kernel");
+  }
   dim3 grid(ceil_div(w * (C8 / 8), 256), h, N);
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)ddst, ldddst, choff, H, W, (T*)dsrc, lddsrc, h, w, C8));
   return check_launch("resize_bwd_kernel");
