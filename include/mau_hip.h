@@ -247,6 +247,12 @@ int mau_lstm_bwd(const float* x, const float* w_hh, const float* gates, const fl
                  float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, float* ws, int B, int T, int H,
                  mau_stream_t stream);
 
+/* nn.Linear of TemporalEncoder.fc (src/model.py:27,34): out (N,D) = x (N,F) w^T + b, w (D,F) as torch stores it. */
+int mau_linear_fwd(const float* x, const float* w, const float* b, float* out, int N, int F, int D, mau_stream_t stream);
+/* dx (N,F) (optional, NULL to skip), dw (D,F), db (D) from dout (N,D). */
+int mau_linear_bwd(const float* x, const float* w, const float* dout, float* dx, float* dw, float* db, int N, int F,
+                   int D, mau_stream_t stream);
+
 /* ---- loss: F.mse_loss (src/utils/losses.py:27-39) -------------------------- */
 /* loss[0] = mean((out-tgt)^2) (fp64 accumulation, fixed order); dout (optional) = 2*(out-tgt)/n;
  * partial: fp64 workspace of mau_mse_blocks(n) elements. */

@@ -75,6 +75,8 @@ PROTOTYPES = {
     "mau_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "mau_lstm_bwd_ws_elems": (_sz, [_i, _i, _i]),
     "mau_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "mau_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "mau_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "mau_mse_blocks": (_i, [_i64]),
     "mau_l1_gradient_blocks": (_i, [_i64]),
     "mau_l1_gradient_loss": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i, _i, _i, _p]),

@@ -797,6 +797,35 @@ class LSTMLast(torch.autograd.Function):
         return None, dw_ih.view(wshape), dw_hh, db_ih, db_hh            # (the series is data: no gradient w.r.t. x)
 
 
+class Linear(torch.autograd.Function):
+    """nn.Linear (TemporalEncoder.fc, src/model.py:27,34) on the HIP path: out = x w^T + b."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _require_cuda(x, "Linear")
+        x = x.contiguous().float()
+        N, F = x.shape
+        D = w.shape[0]
+        out = torch.empty((N, D), dtype=torch.float32, device=x.device)
+        wc = w.detach().contiguous().float()
+        call("mau_linear_fwd", x.data_ptr(), wc.data_ptr(), b.detach().data_ptr() if b is not None else None, out.data_ptr(), N, F, D, _stream())
+        ctx.save_for_backward(x, wc)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wc = ctx.saved_tensors
+        N, F = x.shape
+        D = wc.shape[0]
+        dout = dout.contiguous().float()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw, db = torch.empty_like(wc), torch.empty(D, dtype=torch.float32, device=x.device)
+        call("mau_linear_bwd", x.data_ptr(), wc.data_ptr(), dout.data_ptr(), dx.data_ptr() if dx is not None else None, dw.data_ptr(),
+             db.data_ptr(), N, F, D, _stream())
+        return dx, dw, (db if ctx.has_bias else None)
+
+
 # --------------------------------------------------------------------------- #
 # MSE criterion
 # --------------------------------------------------------------------------- #

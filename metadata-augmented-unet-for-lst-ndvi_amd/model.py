@@ -111,7 +111,7 @@ class TemporalEncoder(nn.Module):
         else:   # hidden sizes beyond one gate row per thread: the library LSTM (SURVEY 8a row a19 allows it)
             _, (h_n, _) = lstm(x.unsqueeze(-1))
             h = h_n[-1]
-        return torch.nn.functional.linear(h, self.fc.weight, self.fc.bias)
+        return F_.Linear.apply(h, self.fc.weight, self.fc.bias)
 
 
 class MetadataEncoder(nn.Module):
