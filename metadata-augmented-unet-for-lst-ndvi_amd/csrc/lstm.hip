@@ -32,8 +32,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
 #else
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+// (v_rcp_f32 directly: __frcp_rn expands to a 12-instruction IEEE division)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 #endif
 
 // value of lane (quad base + J) of every quad, for all four lanes of the quad (DPP quad_perm: no LDS, no barrier)
@@ -41,28 +42,52 @@ template <int J>
 __device__ __forceinline__ float quad_bcast(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), J * 0x55, 0xf, 0xf, true));
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the lane quad, in every lane of the quad: butterfly with quad_perm [1,0,3,2] then [2,3,0,1]
 __device__ __forceinline__ float quad_sum(float v) {
-  return (quad_bcast<0>(v) + quad_bcast<1>(v)) + (quad_bcast<2>(v) + quad_bcast<3>(v));
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  return v;
+}
+
+// sum over each aligned group of 16 lanes, in all 16: the quad butterfly, then row rotations by 4 and 8 (DPP row_ror)
+__device__ __forceinline__ float row16_sum(float v) {
+  v = quad_sum(v);
+  v += dpp_mov<0x124>(v);
+  v += dpp_mov<0x128>(v);
+  return v;
 }
 
 // x (B,T); w_ih (4H) [input_size 1]; w_hh (4H,H); b_ih, b_hh (4H); h_last (B,H);
 // gates (B,T,4H) post-activation i,f,g,o and cells (B,T,H) are written when non-null (saved for backward).
-// Thread 4u + q owns gate row q*H + u: the four gates of a unit sit in one lane QUAD, meet through DPP broadcasts (no LDS
-// round trip, no second barrier) and every lane of the quad carries the unit's cell state redundantly.  One barrier per
-// step (h_t is double-buffered in LDS).
+// Thread 4u + q: the lane QUAD of unit u.  Lane q multiplies the q-th QUARTER of h with the matching quarter of ALL FOUR gate
+// rows of the unit (4 x HP/4 weights in registers) -- it reads HP/4 values of h from LDS instead of HP (the broadcast reads
+// of h were the step's longest pole: the LDS pipe serves 16 B x 16 lanes per cycle whether or not the addresses coincide)
+// -- the four partial products of a gate are added inside the quad (DPP), lane q then applies gate q's nonlinearity, the
+// activations are exchanged inside the quad and every lane carries the unit's cell state redundantly.  One barrier per step.
 template <int HP>
 __global__ __launch_bounds__(4 * HP) void lstm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_ih,
                                                          const float* __restrict__ w_hh, const float* __restrict__ b_ih,
                                                          const float* __restrict__ b_hh, float* __restrict__ h_last,
                                                          float* __restrict__ gates, float* __restrict__ cells, int T, int H) {
+  constexpr int QK = HP / 4;                           // k values per lane
+  static_assert(QK % 4 == 0, "quarter of h in 16-byte reads");
   __shared__ __attribute__((aligned(16))) float hs[2][HP];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int u = tid >> 2, q = tid & 3;                // unit u, gate q (i, f, g, o)
+  const int u = tid >> 2, q = tid & 3;                // unit u; lane q: k quarter q, nonlinearity of gate q (i, f, g, o)
   const bool live = u < H;
-  const int row = q * H + u;
-  f32x2 w[HP / 2];                                     // (pairs: the dot product runs on v_pk_fma_f32)
+  f32x2 w[4][QK / 2];                                  // w[g][kk]: row g*H + u, k = q*QK + kk (pairs: v_pk_fma_f32)
 #pragma unroll
-  for (int k = 0; k < HP; ++k) w[k >> 1][k & 1] = (live && k < H) ? w_hh[(size_t)row * H + k] : 0.f;
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int kk = 0; kk < QK; ++kk) {
+      const int k = q * QK + kk;
+      w[g][kk >> 1][kk & 1] = (live && k < H) ? w_hh[(size_t)(g * H + u) * H + k] : 0.f;
+    }
+  const int row = q * H + u;                           // the gate row whose activation this lane produces
   const float wi = live ? w_ih[row] : 0.f;
   const float bias = live ? b_ih[row] + b_hh[row] : 0.f;
   const float gsc = q == 2 ? 2.f : 1.f;                // tanh(x) = 2 sigmoid(2x) - 1: one exp + rcp for every gate
@@ -73,15 +98,30 @@ __global__ __launch_bounds__(4 * HP) void lstm_fwd_kernel(const float* __restric
   float xt = xb[0];
   for (int t = 0; t < T; ++t) {
     const float xn = t + 1 < T ? xb[t + 1] : 0.f;      // next input in flight while this step multiplies
-    const float* hcur = hs[t & 1];
-    f32x2 a0 = {fmaf(wi, xt, bias), 0.f}, a1 = {0.f, 0.f};
+    const float* hq = hs[t & 1] + q * QK;
+    f32x2 p[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-    for (int k = 0; k < HP; k += 4) {
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(&hcur[k]);
-      a0 = __builtin_elementwise_fma(w[k >> 1], hv.xy, a0);
-      a1 = __builtin_elementwise_fma(w[(k >> 1) + 1], hv.zw, a1);
+    for (int kk = 0; kk < QK; kk += 4) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(&hq[kk]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#ifdef MAU_LSTM_PACKED
+        p[g] = __builtin_elementwise_fma(w[g][kk >> 1], hv.xy, p[g]);
+        p[g] = __builtin_elementwise_fma(w[g][(kk >> 1) + 1], hv.zw, p[g]);
+#else
+        // scalar FMAs on purpose: a wave64 v_pk_fma_f32 costs more issue cycles than the two v_fma_f32 it replaces
+        p[g][0] = fmaf(w[g][kk >> 1][0], hv[0], p[g][0]);
+        p[g][1] = fmaf(w[g][kk >> 1][1], hv[1], p[g][1]);
+        p[g][0] = fmaf(w[g][(kk >> 1) + 1][0], hv[2], p[g][0]);
+        p[g][1] = fmaf(w[g][(kk >> 1) + 1][1], hv[3], p[g][1]);
+#endif
+      }
     }
-    const float pre = (a0[0] + a0[1]) + (a1[0] + a1[1]);
+    // gate g's pre-activation = sum over the quad of p[g]; lane q keeps gate q's
+    const float s0 = quad_sum(p[0][0] + p[0][1]), s1 = quad_sum(p[1][0] + p[1][1]);
+    const float s2 = quad_sum(p[2][0] + p[2][1]), s3 = quad_sum(p[3][0] + p[3][1]);
+    const float dot = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
+    const float pre = dot + fmaf(wi, xt, bias);
     const float sg = sigmoidf_(gsc * pre);
     const float av = q == 2 ? fmaf(2.f, sg, -1.f) : sg;
     if (gates != nullptr && live) gates[((size_t)b * T + t) * 4 * H + row] = av;
@@ -100,72 +140,153 @@ __global__ __launch_bounds__(4 * HP) void lstm_fwd_kernel(const float* __restric
 
 // dh_last (B,H) -> dpre_all (B,T,4H) pre-activation gate gradients + per-sample partials dwih_p (B,4H), db_p (B,4H).
 // Thread 4k + q owns column k of gate q: W_hh[q*H + j][k], j = 0..H.  Per step, lane q of a quad turns (dh[k], dc[k])
-// -- both carried redundantly by the quad -- into the pre-activation gradient of ITS gate, publishes it in LDS (double
-// buffered: one barrier per step), multiplies its column with the gate's gradient vector, and the four partial products
-// of unit k are added inside the quad (DPP), which leaves dh_{t-1}[k] in the registers of the lanes that need it next.
+// -- both carried redundantly by the quad -- into the pre-activation gradient of ITS gate, publishes it in LDS, multiplies
+// its column with the gate's gradient vector, and the four partial products of unit k are added inside the quad (DPP),
+// which leaves dh_{t-1}[k] in the registers of the lanes that need it next.  One barrier per step.
+// The step loop touches NO global memory: the saved activations of LSTM_BS steps are staged into LDS a whole block ahead
+// (plain loads into registers at one block boundary, written to LDS at the next: their latency is a block old by then),
+// and the block's gradients leave from LDS in bulk.  (With per-step loads and stores the compiler's s_waitcnt vmcnt(0)
+// at the loop head waited out an HBM store round trip in every one of the 828 steps: 1.3 us per step.)
+constexpr int LSTM_BS = 8;
 template <int HP>
 __global__ __launch_bounds__(4 * HP) void lstm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w_hh,
                                                          const float* __restrict__ gates, const float* __restrict__ cells,
                                                          const float* __restrict__ dh_last, float* __restrict__ dpre_all,
                                                          float* __restrict__ dwih_p, float* __restrict__ db_p, int T, int H) {
-  __shared__ __attribute__((aligned(16))) float dpre[2][4 * HP];  // pre-activation gate gradients of a step, [gate][unit]
+  constexpr int S = LSTM_BS, NT = 4 * HP, ROW = 5 * HP;            // staged row: 4*HP gates in [unit][gate] order | HP cells
+  constexpr int GP = HP + 8, OROW = 4 * GP;                         // gradient row: [gate][GP]; the pitch puts the four gates'
+                                                                    // 16-byte reads of a lane group on distinct banks (with
+                                                                    // pitch HP = 96 gates 0/2 and 1/3 collide: every read 2x)
+  constexpr int NLD = S * ROW / NT;                                 // staged values per thread and block (20)
+  static_assert(S * ROW % NT == 0, "staging loop");
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  float* inb = lsm;                                                 // [2][S][ROW]
+  float* xin = inb + 2 * S * ROW;                                   // [2][S]
+  float* outb = xin + 2 * S;                                        // [2][S][OROW], [gate][unit] order (the dot's read layout)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int k = tid >> 2, q = tid & 3;
   const bool live = k < H;
-  f32x2 wt[HP / 2];
+  // product role: the 16 lanes that hold units 4G .. 4G+3 split the 4*HP gate gradients into 16 parts of PK; lane l holds
+  // the weights of its part for all four units: wt[u][i] = W_hh[g*H + j0 + i][4G + u], g = l / 4, j0 = (l % 4) * PK
+  constexpr int PK = HP / 4;
+  static_assert(PK % 4 == 0, "part of the gradient vector in 16-byte reads");
+  const int q16 = (tid >> 2) & 3;                                    // k - 4G
+  const int l16 = tid & 15, G4 = (tid >> 4) * 4, pg = l16 >> 2, pj0 = (l16 & 3) * PK;
+  float wt[4][PK];
 #pragma unroll
-  for (int j = 0; j < HP; ++j) wt[j >> 1][j & 1] = (live && j < H) ? w_hh[(size_t)(q * H + j) * H + k] : 0.f;
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int i = 0; i < PK; ++i)
+      wt[u][i] = (G4 + u < H && pj0 + i < H) ? w_hh[(size_t)(pg * H + pj0 + i) * H + G4 + u] : 0.f;
   float dc = 0.f, dwi = 0.f, dbv = 0.f;
   float dh = live ? dh_last[(size_t)b * H + k] : 0.f;
-  for (int i = tid; i < 2 * 4 * HP; i += 4 * HP) (&dpre[0][0])[i] = 0.f;
-  __syncthreads();
   const float* xb = x + (size_t)b * T;
   const float* gb = gates + (size_t)b * T * 4 * H;
   const float* cb = cells + (size_t)b * T * H;
-  // Saved activations are read ONE STEP AHEAD into registers (a dependent global load per step would cost its full
-  // latency 828 times): this lane's gate of step t (the quad holds i, f, g, o), c_t and c_{t-1}.
-  float av = 0.f, ct = 0.f, cp = 0.f, xt = xb[T - 1];
-  if (live) {
-    av = gb[(size_t)(T - 1) * 4 * H + q * H + k];
-    ct = cb[(size_t)(T - 1) * H + k];
-    if (T > 1) cp = cb[(size_t)(T - 2) * H + k];
-  }
   float* dpb = dpre_all + (size_t)b * T * 4 * H;
-  for (int t = T - 1; t >= 0; --t) {
-    // ---- prefetch for step t-1 ----
-    float nav = 0.f, ncp = 0.f, nxt = 0.f;
-    if (t > 0) {
-      nxt = xb[t - 1];
-      if (live) {
-        nav = gb[(size_t)(t - 1) * 4 * H + q * H + k];
-        if (t > 1) ncp = cb[(size_t)(t - 2) * H + k];
+  const int nblk = (T + S - 1) / S;
+
+  // staging of block j (steps t0 = T-1-S*j, t0-1, ...): thread i-th value = element e = tid + i*NT of the padded [S][5*HP]
+  // index space (compile-time divisors; coalesced for H == HP); pad units and steps before the sequence start read as zero
+  float st[NLD], sx = 0.f;
+  auto stage_load = [&](int j) {
+    const int t0 = T - 1 - S * j;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * NT, sl = e / ROW, r = e % ROW, t = t0 - sl;
+      const int g = r / HP, u = r % HP;                 // g < 4: gate g of unit u; g == 4: cell of unit u
+      float v = 0.f;
+      if (t >= 0 && u < H) v = g < 4 ? gb[(size_t)t * 4 * H + g * H + u] : cb[(size_t)t * H + u];
+      st[i] = v;
+    }
+    sx = (tid < S && t0 - tid >= 0) ? xb[t0 - tid] : 0.f;
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * NT, sl = e / ROW, r = e % ROW;
+      const int g = r / HP, u = r % HP;
+      inb[(buf * S + sl) * ROW + (g < 4 ? 4 * u + g : 4 * HP + u)] = st[i];        // gate g, unit u -> 4u + g
+    }
+    if (tid < S) xin[buf * S + tid] = sx;
+  };
+  for (int i = tid; i < 2 * S * ROW; i += NT) inb[i] = 0.f;          // pad units stay zero
+  for (int i = tid; i < 2 * S * OROW; i += NT) outb[i] = 0.f;
+  __syncthreads();
+  stage_load(0);
+  stage_write(0);
+  if (nblk > 1) stage_load(1);
+#pragma unroll 1
+  for (int j = 0; j < nblk; ++j) {
+    const int buf = j & 1, t0 = T - 1 - S * j;
+    __syncthreads();                                  // everyone is done with in-buffer buf^1 (block j-1) and out-buffer buf^1
+    if (j + 1 < nblk) stage_write(buf ^ 1);           // block j+1 (loaded a block ago)
+    if (j + 2 < nblk) stage_load(j + 2);
+    if (j > 0) {                                      // block j-1's gradients leave in bulk (coalesced)
+      const int tp = t0 + S;                          // first step of block j-1
+      for (int e = tid; e < S * 4 * HP; e += NT) {
+        const int sl = e / (4 * HP), r = e % (4 * HP), g = r / HP, u = r % HP;
+        if (u < H) dpb[(size_t)(tp - sl) * 4 * H + g * H + u] = outb[((buf ^ 1) * S + sl) * OROW + g * GP + u];
       }
     }
-    const float ig = quad_bcast<0>(av), fg = quad_bcast<1>(av), gg = quad_bcast<2>(av), og = quad_bcast<3>(av);
-    const float tc = tanhf_(ct);
-    const float dct = fmaf(dh * og, 1.f - tc * tc, dc);
-    // pre-activation gradient of this lane's gate: i, f: d * s(1-s); g: d * (1-g^2); o: d * s(1-s)
-    const float up = q == 0 ? dct * gg : (q == 1 ? dct * cp : (q == 2 ? dct * ig : dh * tc));
-    const float der = q == 2 ? 1.f - av * av : av * (1.f - av);
-    const float dp = live ? up * der : 0.f;
-    dc = dct * fg;
-    float* dcur = dpre[t & 1];
-    dcur[q * HP + k] = dp;
-    if (live) dpb[(size_t)t * 4 * H + q * H + k] = dp;
-    dwi = fmaf(dp, xt, dwi);
-    dbv += dp;
-    __syncthreads();
-    f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
+    __syncthreads();                                  // in-buffer buf^1 written: step S-1 reads its slot 0 (c_{t-1})
+    const int ns = min(S, t0 + 1);
+    // Everything of a step that does NOT depend on (dh, dc) is computed one step ahead, in the shadow of the previous
+    // step's product: the per-step dependency chain is  dh -> fma -> mul -> ds_write -> barrier -> product -> quad sum.
+    //   dct = dh * A + dc,  dp = (q == 3 ? dh : dct) * Bq,  dc' = dct * fg
+    //   A = o (1 - tanh(c)^2);  Bq = {g, c_prev, i, tanh(c)}[q] * (q == 2 ? 1 - a^2 : a (1 - a)),  a = this lane's gate
+    auto coeffs = [&](int sl, float& A, float& Bq, float& fgv, float& xv) {
+      const int t = t0 - sl;
+      const float* row = inb + (buf * S + sl) * ROW;
+      const float av = row[tid];
+      const float ct = row[4 * HP + k];
+      // c_{t-1}: next slot of this block, or slot 0 of the next block's buffer; 0 before the sequence start
+      const float cp = t == 0 ? 0.f : (sl + 1 < S ? row[ROW + 4 * HP + k] : inb[((buf ^ 1) * S) * ROW + 4 * HP + k]);
+      xv = xin[buf * S + sl];
+      const float ig = quad_bcast<0>(av), gg = quad_bcast<2>(av), og = quad_bcast<3>(av);
+      fgv = quad_bcast<1>(av);
+      const float tc = tanhf_(ct);
+      A = og * (1.f - tc * tc);
+      const float up = q == 0 ? gg : (q == 1 ? cp : (q == 2 ? ig : tc));
+      const float der = q == 2 ? 1.f - av * av : av * (1.f - av);
+      Bq = live ? up * der : 0.f;
+    };
+    float A, Bq, fgv, xt;
+    coeffs(0, A, Bq, fgv, xt);
+#pragma unroll 1
+    for (int sl = 0; sl < ns; ++sl) {
+      const float dct = fmaf(dh, A, dc);
+      const float dp = (q == 3 ? dh : dct) * Bq;
+      dc = dct * fgv;
+      float* dcur = outb + (buf * S + sl) * OROW;
+      dcur[q * GP + k] = dp;
+      dwi = fmaf(dp, xt, dwi);
+      dbv += dp;
+      float nA = 0.f, nB = 0.f, nf = 0.f, nx = 0.f;
+      if (sl + 1 < ns) coeffs(sl + 1, nA, nB, nf, nx);      // (reads only the staged history: independent of this step)
+      __syncthreads();
+      float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < HP; j += 4) {
-      const f32x4 d = *reinterpret_cast<const f32x4*>(&dcur[q * HP + j]);
-      p0 = __builtin_elementwise_fma(wt[j >> 1], d.xy, p0);
-      p1 = __builtin_elementwise_fma(wt[(j >> 1) + 1], d.zw, p1);
+      for (int i = 0; i < PK; i += 4) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(&dcur[pg * GP + pj0 + i]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) p[u] = fmaf(wt[u][i + e], d[e], p[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = row16_sum(p[u]);  // dh_{t-1}[4G + u], in all 16 lanes
+      dh = (q16 & 2) ? ((q16 & 1) ? p[3] : p[2]) : ((q16 & 1) ? p[1] : p[0]);   // this lane's unit: k = 4G + l / 4
+      A = nA, Bq = nB, fgv = nf, xt = nx;
     }
-    dh = quad_sum((p0[0] + p0[1]) + (p1[0] + p1[1]));       // dh_{t-1}[k], in every lane of the quad
-    // ---- rotate: step t-1's cell state is this step's previous cell state ----
-    ct = cp;
-    av = nav, cp = ncp, xt = nxt;
+  }
+  __syncthreads();
+  {                                                   // the last block's gradients
+    const int j = nblk - 1, buf = j & 1, t0 = T - 1 - S * j, ns = min(S, t0 + 1);
+    for (int e = tid; e < ns * 4 * HP; e += NT) {
+      const int sl = e / (4 * HP), r = e % (4 * HP), g = r / HP, u = r % HP;
+      if (u < H) dpb[(size_t)(t0 - sl) * 4 * H + g * H + u] = outb[(buf * S + sl) * OROW + g * GP + u];
+    }
   }
   if (live) {
     dwih_p[(size_t)b * 4 * H + q * H + k] = dwi;
@@ -270,10 +391,23 @@ int mau_lstm_bwd(const float* x, const float* w_hh, const float* gates, const fl
   float* dwih_p = ws + (size_t)B * T * 4 * H;
   float* db_p = dwih_p + (size_t)B * 4 * H;
   float* dwhh_p = db_p + (size_t)B * 4 * H;
-  if (H <= 32) MAU_LAUNCH(lstm_bwd_kernel<32>, dim3(B), dim3(128), 0, st, x, w_hh, gates, cells, dh_last, dpre_all, dwih_p, db_p, T, H);
-  else if (H <= 64) MAU_LAUNCH(lstm_bwd_kernel<64>, dim3(B), dim3(256), 0, st, x, w_hh, gates, cells, dh_last, dpre_all, dwih_p, db_p, T, H);
-  else if (H <= 96) MAU_LAUNCH(lstm_bwd_kernel<96>, dim3(B), dim3(384), 0, st, x, w_hh, gates, cells, dh_last, dpre_all, dwih_p, db_p, T, H);
-  else MAU_LAUNCH(lstm_bwd_kernel<128>, dim3(B), dim3(512), 0, st, x, w_hh, gates, cells, dh_last, dpre_all, dwih_p, db_p, T, H);
+  auto bwd_lds = [](int HP) { return (size_t)(2 * LSTM_BS * 5 * HP + 2 * LSTM_BS + 2 * LSTM_BS * 4 * (HP + 8)) * sizeof(float); };
+#define MAU_LSTM_BWD(HP_)                                                                                                       \
+  do {                                                                                                                          \
+    static bool attr_set = false;                                                                                               \
+    if (!attr_set) {                                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<HP_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)bwd_lds(HP_));                                                                             \
+      attr_set = true;                                                                                                          \
+    }                                                                                                                           \
+    MAU_LAUNCH(lstm_bwd_kernel<HP_>, dim3(B), dim3(4 * HP_), bwd_lds(HP_), st, x, w_hh, gates, cells, dh_last, dpre_all, dwih_p,  \
+               db_p, T, H);                                                                                                     \
+  } while (0)
+  if (H <= 32) MAU_LSTM_BWD(32);
+  else if (H <= 64) MAU_LSTM_BWD(64);
+  else if (H <= 96) MAU_LSTM_BWD(96);
+  else MAU_LSTM_BWD(128);
+#undef MAU_LSTM_BWD
   const int chunks = lstm_dw_chunks(B, T);
   if (H <= 32) MAU_LAUNCH(lstm_dwhh_kernel<2>, dim3(ceil_div(4 * H, 64), chunks), dim3(256), 0, st, (const float*)dpre_all, gates, cells, dwhh_p, B * T, T, H);
   else if (H <= 96) MAU_LAUNCH(lstm_dwhh_kernel<6>, dim3(ceil_div(4 * H, 64), chunks), dim3(256), 0, st, (const float*)dpre_all, gates, cells, dwhh_p, B * T, T, H);
