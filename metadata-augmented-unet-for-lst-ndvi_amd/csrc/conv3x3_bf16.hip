@@ -45,6 +45,9 @@ __device__ __forceinline__ int halo_swz(int hx) { return (hx >> 3) & 1; }
 template <int TAP, int BN, int MT>
 __device__ __forceinline__ void fetch_tap(bf16x8 (&fb)[2], bf16x8 (&fa)[MT], unsigned b0a, unsigned b1a, const unsigned (&aa)[3]) {
   constexpr int dy = TAP / 3, dx = TAP % 3;
+#ifdef MAU_CONV_ABL_NOREAD          // timing-only ablation: fragments are whatever the registers hold
+  return;
+#endif
   fb[0] = lds_read128<TAP * BN * ROWB>(b0a);
   fb[1] = lds_read128<TAP * BN * ROWB>(b1a);
   fa[0] = lds_read128<(0 * 2 + dy) * HS * ROWB>(aa[dx]);
@@ -53,6 +56,27 @@ __device__ __forceinline__ void fetch_tap(bf16x8 (&fb)[2], bf16x8 (&fa)[MT], uns
     fa[2] = lds_read128<(2 * 2 + dy) * HS * ROWB>(aa[dx]);
     fa[3] = lds_read128<(3 * 2 + dy) * HS * ROWB>(aa[dx]);
   }
+}
+// one fragment of a tap: I = 0, 1 -> the two weight fragments, I >= 2 -> pixel fragment I - 2
+template <int TAP, int BN, int MT, int I>
+__device__ __forceinline__ void fetch_piece(bf16x8 (&fb)[2], bf16x8 (&fa)[MT], unsigned b0a, unsigned b1a, const unsigned (&aa)[3]) {
+  constexpr int dy = TAP / 3, dx = TAP % 3;
+#ifdef MAU_CONV_ABL_NOREAD
+  return;
+#endif
+  if constexpr (I == 0) fb[0] = lds_read128<TAP * BN * ROWB>(b0a);
+  else if constexpr (I == 1) fb[1] = lds_read128<TAP * BN * ROWB>(b1a);
+  else fa[I - 2] = lds_read128<((I - 2) * 2 + dy) * HS * ROWB>(aa[dx]);
+}
+// Fragment r of a tap in NEED order of the MFMA sequence (mt, nt) = (0,0), (0,1), (1,0), ...: weight 0, pixel 0, weight 1,
+// pixel 1, pixel 2, ...  DS operations return in issue order, so "fragment r has landed" is a counted lgkmcnt.
+template <int TAP, int BN, int MT, int R>
+__device__ __forceinline__ void fetch_need(bf16x8 (&fb)[2], bf16x8 (&fa)[MT], unsigned b0a, unsigned b1a, const unsigned (&aa)[3]) {
+  fetch_piece<TAP, BN, MT, (R == 0 ? 0 : R == 1 ? 2 : R == 2 ? 1 : R)>(fb, fa, b0a, b1a, aa);
+}
+template <int N>
+__device__ __forceinline__ void landed(bf16x8& a, bf16x8& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 // wait until at most N of this wave's LDS operations are outstanding; the fragments of the tap about to be multiplied
 template <int N, int MT>
@@ -63,6 +87,80 @@ __device__ __forceinline__ void land(bf16x8 (&fb)[2], bf16x8 (&fa)[MT]) {
   else
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]) : "n"(N));
 }
+
+// ---- The multiply schedule of one stage (16 input channels x 9 taps) of a wave ----
+// Taps are walked dx-major.  For one dx the pixel fragment of halo ROW PAIR r (rows r, r + 1 of the wave's strip, shifted by
+// dx) is the operand of every (tile mt, dy) with 2 * mt + dy = r -- up to two tiles -- so it is read ONCE: 2 * MT + 1
+// pixel fragments per dx instead of 3 * MT, 9 instead of 12 for MT = 4 (LDS reads are what the kernel's power goes into,
+// after the MFMAs: see DESIGN.md, "the clock is the bound").  A fragment read is issued LEAD MFMAs before its first use, in
+// need order; DS operations return in order, so "fragment k has landed" is a counted lgkmcnt.
+template <int MT>
+struct StageSched {
+  static constexpr int NG = 3, ROWS = 2 * MT + 1;
+  static constexpr int NM = 18 * MT;                    // MFMAs of a stage
+  static constexpr int NR = NG * (ROWS + 6);            // fragment reads of a stage
+#ifdef MAU_CONV_LEAD
+  static constexpr int LEAD = MAU_CONV_LEAD, RING = MAU_CONV_RING, BRING = MAU_CONV_BRING;
+#else
+  static constexpr int LEAD = 8;                        // MFMAs between a fragment's read and its first use
+  static constexpr int RING = 6, BRING = 10;            // pixel / weight fragment registers (rings in read order)
+#endif
+  struct MF { int g, r, mt, dy, nt, ka, kb; };          // ka / kb: read index of its pixel / weight fragment
+  struct RD { int isA, g, r, dy, nt, need, last, iss, seq; };   // need / last: first / last MFMA using it; iss: issued after MFMA iss (-1: stage head)
+  MF mf[NM] = {};
+  RD rd[NR] = {};
+  int lo[NM + 1] = {};                                  // reads issued after MFMA M: [lo[M + 1], lo[M + 2]) ... see rd_lo()
+  constexpr StageSched() {
+    int a_idx[NG][ROWS] = {}, b_idx[NG][3][2] = {};
+    for (int g = 0; g < NG; ++g) {
+      for (int r = 0; r < ROWS; ++r) a_idx[g][r] = -1;
+      for (int dy = 0; dy < 3; ++dy) b_idx[g][dy][0] = b_idx[g][dy][1] = -1;
+    }
+    int m = 0, k = 0, aseq = 0, bseq = 0;
+    for (int g = 0; g < NG; ++g)
+      for (int r = 0; r < ROWS; ++r)
+        for (int which = 0; which < 2; ++which) {       // the tiles row pair r belongs to: (r/2, dy 0 | 1), then (r/2 - 1, dy 2)
+          const int dy = (r & 1) ? 1 : (which == 0 ? 0 : 2);
+          const int mt = (r & 1) ? (r - 1) / 2 : (which == 0 ? r / 2 : r / 2 - 1);
+          if ((r & 1) && which == 1) continue;
+          if (mt < 0 || mt >= MT) continue;
+          for (int nt = 0; nt < 2; ++nt) {
+            if (b_idx[g][dy][nt] < 0) {
+              rd[k] = {0, g, r, dy, nt, m, m, 0, bseq++};
+              b_idx[g][dy][nt] = k++;
+            }
+            if (a_idx[g][r] < 0) {
+              rd[k] = {1, g, r, dy, nt, m, m, 0, aseq++};
+              a_idx[g][r] = k++;
+            }
+            mf[m] = {g, r, mt, dy, nt, a_idx[g][r], b_idx[g][dy][nt]};
+            rd[a_idx[g][r]].last = m;
+            rd[b_idx[g][dy][nt]].last = m;
+            ++m;
+          }
+        }
+    for (int i = 0; i < NR; ++i) rd[i].iss = rd[i].need - LEAD < -1 ? -1 : rd[i].need - LEAD;
+    int c = 0;                                          // lo[M] = number of reads issued before MFMA M is issued
+    for (int M = 0; M <= NM; ++M) {
+      while (c < NR && rd[c].iss < M) ++c;
+      lo[M] = c;
+    }
+  }
+  constexpr bool ok() const {                           // counts, order, and the register ring never overwrites a live fragment
+    int m = 0, k = 0;
+    for (int i = 0; i < NM; ++i) m += mf[i].mt >= 0;
+    for (int i = 0; i < NR; ++i) {
+      if (i > 0 && (rd[i].need < rd[i - 1].need || rd[i].iss < rd[i - 1].iss)) return false;
+      for (int j = 0; j < i; ++j)                       // the register this read lands in: its previous fragment is done
+        if (rd[j].isA == rd[i].isA && rd[j].seq + (rd[i].isA ? RING : BRING) == rd[i].seq && rd[j].last > rd[i].iss) return false;
+      ++k;
+    }
+    return m == NM && k == NR && lo[NM] == NR;
+  }
+};
+
+template <int MT>
+inline constexpr StageSched<MT> kStageSched{};
 
 // One (pixel tile, cout tile) work item.
 struct Item {
@@ -86,7 +184,7 @@ struct Geo {
   static constexpr int TOT_Q = HALO_Q + W_Q;
   static constexpr int PER_WAVE = (TOT_Q + NW - 1) / NW;       // every wave issues exactly PER_WAVE DMAs per stage:
   static constexpr int STAGE = PER_WAVE * NW * 1024;           // slots >= TOT_Q are padding fed from the zero page
-  static_assert(PER_WAVE <= 9, "one DMA per tap");
+  static_assert(PER_WAVE <= 18, "at most two DMAs per tap");
   static constexpr size_t LDS = 2 * (size_t)STAGE;
   static_assert(NW % WN == 0 && (size_t)NW * 32 * 64 * 2 <= STAGE, "epilogue staging must fit one stage buffer");
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -124,11 +222,35 @@ __device__ __forceinline__ void dma_issue(const LoaderArgs la, unsigned long lon
   const bool is_t = valid & (c < ulim);
   const bool is_e = valid & halo & ((unsigned)(c - la.Ctot) < (unsigned)la.E);
   const unsigned long long src = is_t ? pt : (is_e ? pe : la.zero_a);
+#ifdef MAU_CONV_ABL_ADDRONLY        // timing-only: the address arithmetic without the transfer
+  asm volatile("" ::"v"(src), "v"(lds_dst));
+#else
   __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)lds_dst, 16, 0, 0);
+#endif
 }
 
-template <int BN, int MT, int NW, int EPI, bool F16>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
+// timing-only ablations (scripts/build_variants.sh): results are garbage, the instruction streams are what is measured
+#ifdef MAU_CONV_ABL_NODMA
+constexpr bool ABL_NODMA = true;
+#else
+constexpr bool ABL_NODMA = false;
+#endif
+// The same wave-DMA through a buffer resource: address = base (SGPR resource) + soff (SGPR: the stage's channel / slab
+// offset) + voff (per lane, constant over the stages of an item); a lane whose voff is 0xffffffff is out of range and
+// receives zeros (hardware range check: the zero padding of the convolution and of the slot grid, no zero page).  One
+// vector instruction per DMA instead of ~20 (64-bit multiply-add, range tests, three-way select): in this kernel VALU
+// instructions cost clock, not only issue slots ("the clock is the bound").
+typedef __attribute__((address_space(3))) void* lds_vptr;
+__device__ __forceinline__ void dma_issue_buf(__amdgpu_buffer_rsrc_t rs, int voff, int soff, unsigned char* lds_dst) {
+#ifdef MAU_CONV_ABL_ADDRONLY
+  asm volatile("" ::"v"(voff), "s"(soff), "v"(lds_dst));
+#else
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)lds_dst, 16, voff, soff, 0, 0);
+#endif
+}
+
+template <int BN, int MT, int NW, int EPI, bool F16, bool FAST>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
   using G = Geo<BN, MT, NW>;
   constexpr int WN = G::WN, WM = G::WM, TH = G::TH, HPIX = G::HPIX, HALO_Q = G::HALO_Q, HALO_BYTES = G::HALO_BYTES;
   constexpr int TOT_Q = G::TOT_Q, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE;
@@ -176,31 +298,41 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
   // decoder, reference src/model.py:279-282, and fuse_embeddings :248-259, never materialised):
   //   [0, C0) from x (pixel stride ldx) | [C0, C0 + C1) from x1 (ldx1) | [C0 + C1, C0 + C1 + E) from emb[n] | zero page.
   // A stage is one 16-channel chunk; with two tensors C0 % 16 == 0, so the tensor a chunk reads is wave-uniform.
-  int slot_hp[PER_WAVE];            // halo: pixel index inside the halo tile (or -1); weights: row = tap*BN + co
-  int slot_c[PER_WAVE];             // 8 * logical 16-byte half
+  // slot j of this lane: hp = halo pixel index inside the halo tile (or -1) / weight row = tap*BN + co; c = 8 * logical
+  // 16-byte half.  Recomputed where needed (once per item, and per DMA on the general path) instead of held in 2 * PER_WAVE
+  // registers across the K loop.
   const size_t w_stage_stride = (size_t)9 * p.CoutPad * KC;
   const int Ctot = p.C0 + p.C1;     // tensor channels; the broadcast embedding follows
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
+  auto slot_of = [wave, lane](int j, int& hp_or_row, int& c) {
     const int q = wave + j * NW;
-    slot_hp[j] = -1;
-    slot_c[j] = 0;
+    hp_or_row = -1;
+    c = 0;
     if (q < HALO_Q) {
       const int slot = q * 64 + lane;
       const int hp = slot >> 1, ph = slot & 1;
-      slot_c[j] = 8 * (ph ^ halo_swz(hp % HS));
-      slot_hp[j] = hp < HPIX ? hp : -1;
+      c = 8 * (ph ^ halo_swz(hp % HS));
+      hp_or_row = hp < HPIX ? hp : -1;
     } else if (q < TOT_Q) {
       const int slot = (q - HALO_Q) * 64 + lane;
       const int row = slot >> 1, ph = slot & 1;
-      slot_c[j] = 8 * (ph ^ ((row >> 3) & 1));
-      slot_hp[j] = row;
+      c = 8 * (ph ^ ((row >> 3) & 1));
+      hp_or_row = row;
     }
-  }
+  };
 
   // per-lane source offsets of the item being LOADED (constant over its stages); -1 = zero page
   //   halo slot: linear pixel index (n*H + gy)*W + gx;   weight slot: element offset of the row inside a chunk's slab
   int off32[PER_WAVE];
+  // buffer-addressed loader (p.fast): off32 holds BYTE offsets instead -- halo slot: pixel * (2 * ldx) + 2 * channel slot
+  // inside source 0, and the same for source 1 in off1 (only the first HJ slots of a wave can be halo slots);
+  // weight slots (always buffer-addressed): byte offset of the row inside a stage's slab.  -1 = out of range = zeros.
+  constexpr int HJ = (HALO_Q + NW - 1) / NW;
+  int off1[HJ];
+  constexpr bool fast = FAST;        // (p.fast, resolved by the launcher: the two loaders never share a kernel -- with both in one
+                                     //  body the general loader's hoisted 64-bit terms spilled across the K loop of <64,4,8>)
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.N * p.H * p.W * p.ldx * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x1), 0, p.N * p.H * p.W * p.ldx1 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.nChunks * 9 * p.CoutPad * KC * 2, 0x00020000);
   // the kernel arguments the loader needs, as plain scalars (the lambdas below must not keep the argument struct alive in memory)
   const unsigned long long xa = (unsigned long long)p.x, x1a = (unsigned long long)p.x1, wa = (unsigned long long)p.w;
   const unsigned long long zero_a = (unsigned long long)g_zero_page, emb_a = (unsigned long long)p.emb_lp;
@@ -215,18 +347,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     for (int j = 0; j < PER_WAVE; ++j) {
       const int q = wave + j * NW;
       off32[j] = -1;
+      if (j < HJ) off1[j < HJ ? j : 0] = -1;
+      int hp_or_row, sc;
+      slot_of(j, hp_or_row, sc);
       if (q < HALO_Q) {
-        const int hp = slot_hp[j];
+        const int hp = hp_or_row;
         if (hp >= 0) {
           const int gy = it.ty0 + hp / HS - 1, gx = it.tx0 + hp % HS - 1;
-          if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv) off32[j] = (it.n * Hv + gy) * Wv + gx;
+          if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv) {
+            const int pix = (it.n * Hv + gy) * Wv + gx;
+            off32[j] = fast ? pix * (int)(2 * ld0v) + 2 * sc : pix;
+            if (j < HJ) off1[j < HJ ? j : 0] = pix * (int)(2 * ld1v) + 2 * sc;
+          }
         }
       } else if (q < TOT_Q) {
-        const int row = slot_hp[j];
+        const int row = hp_or_row;
         // (the packed rows are pre-permuted: row nt*32 + i of a 64-channel block holds output channel 2*i + nt, so the
         // two accumulator tiles of a lane carry ADJACENT channels -- pack_weights_kernel, conv3x3.hip)
         const int tap = row / BN, co = row % BN;
-        off32[j] = (tap * CoutPadv + it.co0 + co) * KC + slot_c[j];
+        off32[j] = 2 * ((tap * CoutPadv + it.co0 + co) * KC + sc);
       }
     }
   };
@@ -235,10 +374,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
   // One wave-DMA (1 KiB) of a stage: dma_issue() below, a plain function with every operand passed BY VALUE.  (As a
   // [&] lambda, "halo ? (second ? x1 : x) : w" became a load from a SELECTED field of the closure object, which pinned the
   // closure -- and with it wave, slot_c[], off32[] -- in private memory: 300 bytes of scratch traffic inside the K loop.)
+  const int w_stage_bytes32 = 2 * 9 * p.CoutPad * KC;
   const LoaderArgs la = {xa, x1a, wa, 2ull * w_stage_stride, zero_a, ld0v, ld1v, C0v, Ctot, Ev, lim0v, lim1v, hasC1};
 #define MAU_ISSUE_SLOT(J, STAGE_, CHUNK_)                                                                              \
-  dma_issue<KC>(la, embn_a, wave + (J) * NW < HALO_Q, (CHUNK_), slot_c[(J)], off32[(J)],                              \
-                smem + (STAGE_) * STAGE + (wave + (J) * NW) * 1024)
+  {                                                                                                                    \
+    unsigned char* dst_ = smem + (STAGE_) * STAGE + (wave + (J) * NW) * 1024;                                        \
+    const int c0_ = (CHUNK_) * KC;                                                                                     \
+    if ((J) >= HJ || wave + (J) * NW >= HALO_Q) {                                                                      \
+      dma_issue_buf(rs_w, off32[(J)], (CHUNK_) * w_stage_bytes32, dst_);                                              \
+    } else if constexpr (FAST) {                                                                                       \
+      if constexpr ((J) < HJ) {                                                                                        \
+        if (hasC1 && c0_ >= C0v) dma_issue_buf(rs_x1, off1[(J) < HJ ? (J) : 0], 2 * (c0_ - C0v), dst_);                \
+        else dma_issue_buf(rs_x, off32[(J)], 2 * c0_, dst_);                                                          \
+      }                                                                                                                \
+    } else if constexpr ((J) < HJ) {                                                                                   \
+      int hp_, sc_;                                                                                                    \
+      slot_of((J), hp_, sc_);                                                                                          \
+      dma_issue<KC>(la, embn_a, true, (CHUNK_), sc_, off32[(J)], dst_);                                               \
+    }                                                                                                                  \
+  }
 
   // ---- per-lane LDS read addresses: three bases (one per dx) + immediates for (mt, dy); two for the weights ----
   int abase[3];
@@ -305,25 +459,88 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
       const unsigned sbase = lds0 + stage * STAGE;
       const unsigned b0a = sbase + boff0, b1a = sbase + boff1;
       const unsigned aa[3] = {sbase + abase[0], sbase + abase[1], sbase + abase[2]};
-      bf16x8 fb[2][2], fa[2][MT];
-      fetch_tap<0, BN, MT>(fb[0], fa[0], b0a, b1a, aa);
+#ifdef MAU_CONV_DMA_PER_TAP
+      constexpr int DPT = MAU_CONV_DMA_PER_TAP;
+#else
+      constexpr int DPT = PER_WAVE > 9 ? 2 : 1;
+#endif
+      constexpr int DMA_AT = 2 * MT - 2;
+#ifdef MAU_CONV_TAP_LOOP
+      // (the previous loop, kept for A/B timing: tap-major, every tap reads its own 2 + MT fragments)
+      bf16x8 fb[2][2] = {}, fa[2][MT] = {};
+      static_for<0, 2 + MT>([&](auto rc) { fetch_need<0, BN, MT, decltype(rc)::value>(fb[0], fa[0], b0a, b1a, aa); });
 #define MAU_TAP(T)                                                                    \
   {                                                                                   \
-    constexpr int cs = (T)&1;                                                         \
-    if constexpr ((T) < 8) fetch_tap<((T) < 8 ? (T) + 1 : 0), BN, MT>(fb[cs ^ 1], fa[cs ^ 1], b0a, b1a, aa); \
-    land<((T) < 8 ? 2 + MT : 0), MT>(fb[cs], fa[cs]);                                 \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                               \
-      acc[mt][0] = mfma16<F16>(fa[cs][mt], fb[cs][0], acc[mt][0]);                         \
-      acc[mt][1] = mfma16<F16>(fa[cs][mt], fb[cs][1], acc[mt][1]);                         \
-    }                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                \
-    if constexpr ((T) < PER_WAVE) {                                                   \
-      MAU_ISSUE_SLOT((T), stage ^ 1, fchunk);                                         \
+    constexpr int cs = (T)&1, NX = (T) < 8 ? (T) + 1 : 0;                             \
+    static_for<0, 2 * MT>([&](auto ic) {                                              \
+      constexpr int i = decltype(ic)::value, mt = i >> 1, nt = i & 1;                 \
+      constexpr int need = i == 0 ? 1 : i == 1 ? 2 : (i & 1) ? -1 : 2 + (i >> 1);     \
+      if constexpr (need >= 0) {                                                      \
+        constexpr int ahead = (T) < 8 ? (i < 2 + MT ? i : 2 + MT) : 0;                \
+        landed<(1 + MT - need) + ahead>(fa[cs][mt], fb[cs][nt]);                      \
+      }                                                                               \
+      acc[mt][nt] = mfma16<F16>(fa[cs][mt], fb[cs][nt], acc[mt][nt]);                 \
       __builtin_amdgcn_sched_barrier(0);                                              \
-    }                                                                                 \
+      if constexpr ((T) < 8 && i < 2 + MT) {                                          \
+        fetch_need<NX, BN, MT, i>(fb[cs ^ 1], fa[cs ^ 1], b0a, b1a, aa);              \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+      }                                                                               \
+      if constexpr (i == DMA_AT && (T) * DPT < PER_WAVE && !ABL_NODMA) {              \
+        static_for<0, DPT>([&](auto rc) {                                             \
+          constexpr int J = (T) * DPT + decltype(rc)::value;                          \
+          if constexpr (J < PER_WAVE) MAU_ISSUE_SLOT(J, stage ^ 1, fchunk);           \
+        });                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+      }                                                                               \
+    });                                                                               \
   }
       MAU_TAP(0) MAU_TAP(1) MAU_TAP(2) MAU_TAP(3) MAU_TAP(4) MAU_TAP(5) MAU_TAP(6) MAU_TAP(7) MAU_TAP(8)
 #undef MAU_TAP
+#else
+      // The stage's NM MFMAs in StageSched order; between two MFMAs of the wave (an MFMA holds the vector issue port for
+      // 8 of its 32 cycles) go the fragment reads that are LEAD MFMAs from their first use and, every NM / 9 MFMAs, one
+      // wave-DMA of the following stage (a wave-DMA costs its issuing wave 60-185 cycles, MI355X_MICROARCH.md: in a burst
+      // at the head of the stage all eight waves would pay that with the MFMA pipes idle; measured: 2, 3, 9 per slot are
+      // 3-5 % slower than 1).
+      using SS = StageSched<MT>;
+      static_assert(kStageSched<MT>.ok(), "stage schedule");
+      bf16x8 fa[SS::RING] = {}, fb[SS::BRING] = {};
+      auto issue_read = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr typename SS::RD R = kStageSched<MT>.rd[k];
+#ifndef MAU_CONV_ABL_NOREAD
+        if constexpr (R.isA) fa[R.seq % SS::RING] = lds_read128<R.r * HS * ROWB>(aa[R.g]);
+        else if constexpr (R.nt == 0) fb[R.seq % SS::BRING] = lds_read128<(R.dy * 3 + R.g) * BN * ROWB>(b0a);
+        else fb[R.seq % SS::BRING] = lds_read128<(R.dy * 3 + R.g) * BN * ROWB>(b1a);
+#endif
+      };
+      static_for<0, kStageSched<MT>.lo[0]>([&](auto kc) { issue_read(kc); });            // the stage head: everything needed within LEAD
+      static_for<0, SS::NM>([&](auto Mc) {
+        constexpr int M = decltype(Mc)::value;
+        constexpr typename SS::MF f = kStageSched<MT>.mf[M];
+        constexpr int as = kStageSched<MT>.rd[f.ka].seq % SS::RING, bs = kStageSched<MT>.rd[f.kb].seq % SS::BRING;
+        if constexpr (kStageSched<MT>.rd[f.ka].need == M || kStageSched<MT>.rd[f.kb].need == M) {
+          constexpr int kmax = f.ka > f.kb ? f.ka : f.kb;
+          constexpr int allowed = kStageSched<MT>.lo[M] - (kmax + 1);
+          static_assert(allowed >= 0 && allowed <= 15, "lgkmcnt range");
+          landed<allowed>(fa[as], fb[bs]);
+        }
+        acc[f.mt][f.nt] = mfma16<F16>(fa[as], fb[bs], acc[f.mt][f.nt]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kStageSched<MT>.lo[M + 1] > kStageSched<MT>.lo[M]) {
+          static_for<kStageSched<MT>.lo[M], kStageSched<MT>.lo[M + 1]>([&](auto kc) { issue_read(kc); });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        constexpr int SLOT = SS::NM / 9;
+        if constexpr (M % SLOT == SLOT - 2 && (M / SLOT) * DPT < PER_WAVE && !ABL_NODMA) {
+          static_for<0, DPT>([&](auto rc) {
+            constexpr int J = (M / SLOT) * DPT + decltype(rc)::value;
+            if constexpr (J < PER_WAVE) MAU_ISSUE_SLOT(J, stage ^ 1, fchunk);
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+#endif
       stage ^= 1;
       if (more) {                                      // (after the last stage the epilogue's barrier takes this place)
         wait_vmcnt<0>();
@@ -359,6 +576,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
     int xlim[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) xlim[g] = p.W - cur.tx0 - (rowbase[g] & 15);
+#ifdef MAU_CONV_ABL_NOEPI
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+      if (t == 1234.5f) yg[lane] = 1;
+    }
+#else
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int ybase = cur.ty0 + wm * MT * 2 + mt * 2;
@@ -414,6 +643,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 2) void conv3x3_bf16_kernel(
         }
       }
     }
+#endif
     if (EPI == EPI_STATS) {
       // one slab row per (pixel tile, wave row): no cross-wave reduction, hence no barrier and no LDS round trip here
       float* srow = p.slab + ((size_t)cur.pixTile * WM + wm) * 2 * p.CoutPad + cpair;
@@ -442,7 +672,9 @@ static int launch(const ConvP& p, hipStream_t st) {
   using G = Geo<BN, MT, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
     attr_set = true;
   }
@@ -451,6 +683,16 @@ static int launch(const ConvP& p, hipStream_t st) {
   q.tilesX = tilesX;
   q.tilesY = tilesY;
   q.nChunks = ceil_div(p.C0 + p.C1 + p.E, KC);
+  // buffer-addressed halo loads: every 16-channel stage inside one tensor's (zero-padded) pixel row, 31-bit byte offsets
+  const long long px = (long long)p.N * p.H * p.W;
+  const bool one = p.C1 == 0 && p.ldx % KC == 0 && round_up(p.C0, KC) <= p.ldx;
+  const bool two = p.C1 > 0 && p.C0 % KC == 0 && p.C0 <= p.ldx && round_up(p.C1, KC) <= p.ldx1;
+  static const bool no_buf = getenv("MAU_CONV_GENERAL_LOADER") != nullptr;      // A/B: the 64-bit-address loader for every layer
+  q.fast = !no_buf && p.E == 0 && (one || two) && px * p.ldx * 2 < (1ll << 31) && px * p.ldx1 * 2 < (1ll << 31) ? 1 : 0;
+  if ((long long)q.nChunks * 9 * p.CoutPad * KC * 2 >= (1ll << 31)) {
+    set_error("conv3x3_fwd: packed weights beyond 2 GiB");
+    return MAU_ERR_ARG;
+  }
   const int nPixTiles = p.N * tilesX * tilesY;
   const int nCt = p.CoutPad / BN;
   const int nItems = round_up(nPixTiles, 8) * nCt;
@@ -458,22 +700,33 @@ static int launch(const ConvP& p, hipStream_t st) {
   const int per_cu = (int)((160 * 1024) / G::LDS) >= 2 && NW == 4 ? 2 : 1;
   int grid = 256 * per_cu;
   if (grid > nItems) grid = nItems;                    // nItems is a multiple of 8, and so is 256*per_cu
-  MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+  if (q.fast) {
+    MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+  } else {
+    MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+  }
   return check_launch("conv3x3_bf16_kernel");
 }
 
 // Variant choice.  Taller workgroup tiles move fewer LDS-DMA bytes and issue fewer ds_reads per MFMA (measured
 // +5..9 % on full grids), but quarter the number of work items: a layer whose items do not fill the 256 CUs (or that
 // wastes tile rows on a small image) is better off with 16-row tiles.  Score = grid-fill x tile-fill x variant bonus.
-static inline int tile_height(int CoutPad, int N, int H, int W) {
+// (Measured and dropped: <64,4,4> = two 4-wave workgroups per CU drifting apart -- the extra weight-slab DMA traffic cost
+//  more than the overlap gained, 207 vs 182 us on the 64->64 level-0 layer; <*,8,4> = one wave per SIMD with 256
+//  accumulators in AGPRs, 0.48 instead of 0.75 fragment reads per MFMA -- 10-90 % slower, nothing hides its epilogue.)
+struct Variant {
+  int th, nw;                      // tile rows, waves per workgroup
+};
+static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
   static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 64;
   const bool wide = CoutPad % 128 == 0;
   const int nCt = CoutPad / (wide ? 128 : 64);
-  int best = 16;
+  Variant best = {16, wide ? 8 : 4};
   double best_score = -1.0;
   // 64-row tiles exist for the 64-wide variant only (<64,4,8>: the per-MFMA LDS-read and DMA ratios of <128,4,8>)
   for (int th = 16; th <= (wide ? 32 : 64) && th <= th_max; th *= 2) {
-    const int slots = 256 * ((!wide && th == 16) ? 2 : 1);         // <64,2,4> runs two workgroups per CU
+    const int nw = wide || th > 16 ? 8 : 4;
+    const int slots = 256 * (nw == 4 ? 2 : 1);                     // <64,2,4> runs two workgroups per CU
     const long tilesY = ceil_div(H, th), tilesX = ceil_div(W, TW);
     const long items = (long)N * tilesY * tilesX * nCt;
     const double grid_fill = (double)items / (double)(((items + slots - 1) / slots) * slots);
@@ -481,7 +734,7 @@ static inline int tile_height(int CoutPad, int N, int H, int W) {
     const double score = grid_fill * tile_fill * (th == 64 ? 1.10 : th == 32 ? 1.06 : 1.0);
     if (score > best_score) {
       best_score = score;
-      best = th;
+      best = {th, nw};
     }
   }
   return best;
@@ -491,8 +744,9 @@ static inline int tile_height(int CoutPad, int N, int H, int W) {
 // rows of the BatchNorm partial-sum slab: one per (pixel tile, wave row of the workgroup)
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   const int CoutPad = round_up(Cout, 64);
-  const int th = v2::tile_height(CoutPad, N, H, W);
-  const int wm = (CoutPad % 128 != 0 && th >= 32) ? v2::Geo<64, 2, 8>::WM : 4;     // <128,2,8>, <128,4,8>, <64,2,4>: WM = 4; <64,2,8>, <64,4,8>: 8
+  const v2::Variant v = v2::pick_variant(CoutPad, N, H, W);
+  const int th = v.th;
+  const int wm = (CoutPad % 128 != 0 && v.nw == 8) ? v2::Geo<64, 2, 8>::WM : 4;    // <128,*,8>, <64,2,4>: 4 wave rows; <64,2,8>, <64,4,8>: 8
   static_assert(v2::Geo<64, 2, 8>::WM == 8 && v2::Geo<64, 4, 8>::WM == 8 && v2::Geo<64, 4, 8>::TH == 64, "slab rows");
   static_assert(v2::Geo<128, 2, 8>::WM == 4 && v2::Geo<128, 4, 8>::WM == 4 && v2::Geo<64, 2, 4>::WM == 4, "slab rows");
   return wm * N * ceil_div(H, th) * ceil_div(W, v2::TW);
@@ -514,10 +768,10 @@ int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
     set_error("conv3x3_fwd: post_scale/post_shift and the statistics slab are mutually exclusive");
     return MAU_ERR_ARG;
   }
-  const int th = v2::tile_height(p.CoutPad, p.N, p.H, p.W);
-  if (p.CoutPad % 128 == 0) return th == 32 ? launch_epi<128, 4, 8>(p, f16, st) : launch_epi<128, 2, 8>(p, f16, st);
-  if (th == 64) return launch_epi<64, 4, 8>(p, f16, st);
-  return th == 32 ? launch_epi<64, 2, 8>(p, f16, st) : launch_epi<64, 2, 4>(p, f16, st);
+  const v2::Variant v = v2::pick_variant(p.CoutPad, p.N, p.H, p.W);
+  if (p.CoutPad % 128 == 0) return v.th == 32 ? launch_epi<128, 4, 8>(p, f16, st) : launch_epi<128, 2, 8>(p, f16, st);
+  if (v.th == 64) return launch_epi<64, 4, 8>(p, f16, st);
+  return v.th == 32 ? launch_epi<64, 2, 8>(p, f16, st) : launch_epi<64, 2, 4>(p, f16, st);
 }
 
 }  // namespace mau

@@ -27,7 +27,9 @@ def timeit(fn, reps=8):
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}; totf = 0.0
 records = []
 print(f"{'layer':16s} {'Cin':>5s} {'Cout':>5s} {'H':>4s} {'GFLOP':>8s} | {'fwd us':>8s} {'TF/s':>6s} | {'dgrad us':>8s} {'TF/s':>6s} | {'wgrad us':>8s} {'TF/s':>6s} | {'HBM floor us':>11s}")
+_only = [t for t in os.environ.get("LAYERS", "").split(",") if t]
 for name, cin, cout, h in layers:
+    if _only and not any(t in name for t in _only): continue
     N, H, W = B, h, h
     x = torch.randn(N, H, W, F_.pad8(cin), device="cuda").to(dt); x[..., cin:] = 0
     dy = torch.randn(N, H, W, F_.pad8(cout), device="cuda").to(dt)
