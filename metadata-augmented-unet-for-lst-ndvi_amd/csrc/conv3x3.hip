@@ -428,13 +428,8 @@ static size_t wgrad_lds_bytes() {
 
 template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
-  static bool attr_set = false;
   const size_t lds = conv_lds_bytes<T>();
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_kernel<T>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  MAU_LDS_ATTR(lds, &conv3x3_igemm_kernel<T>);
   dim3 grid(p.N * p.tilesX * p.tilesY, p.CoutPad / BN);
   MAU_LAUNCH(conv3x3_igemm_kernel<T>, grid, dim3(NT), lds, st, p);
   return check_launch("conv3x3_igemm_kernel");
@@ -442,15 +437,10 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
 
 template <typename T>
 static int launch_wgrad(const WgradP& p, hipStream_t st) {
-  static bool attr_set = false;
   const size_t lds = wgrad_lds_bytes<T>();
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<T>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  MAU_LDS_ATTR(lds, &conv3x3_wgrad_kernel<T>);
   const int tilesOut = (p.CoutPad / 64) * (p.CinPad / 64);
-  int splits = (256 * 4 + tilesOut - 1) / tilesOut;     // aim at ~4 workgroups per CU
+  int splits = (device_shape().cus * 4 + tilesOut - 1) / tilesOut;     // aim at ~4 workgroups per CU
   if (splits > p.nTiles) splits = p.nTiles;
   if (splits < 1) splits = 1;
   dim3 grid(splits, p.CoutPad / 64, p.CinPad / 64);

@@ -265,14 +265,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
   // (16-bit elements are only moved, never interpreted, outside the matrix core and the epilogue's conversion)
 
   // ---- work items: XCD-aware order; a persistent workgroup walks I = blockIdx.x, +gridDim.x, ...
-  // (gridDim.x is a multiple of 8, so a workgroup stays on one XCD's slice of the item list) ----
+  // (gridDim.x is a multiple of the XCD count, so a workgroup stays on one XCD's slice of the item list) ----
   // Hardware places workgroup id on XCD id % 8.  Every XCD owns a CONTIGUOUS range of pixel tiles (in image order),
   // and its workgroups walk that range together: tiles that share halo rows/columns, and the cout tiles of one pixel
   // tile, are in flight on the same XCD at about the same time, so its L2 serves the overlap instead of HBM
   // (round-robin placement of neighbouring tiles on different XCDs cost 1.17-1.28x the input bytes at level 0).
-  const int tilesPerXcd = (nPixTiles + 7) >> 3;
+  const int xs = p.xcdShift, nx = 1 << xs;           // (3, 8 on an MI355X in SPX mode)
+  const int tilesPerXcd = (nPixTiles + nx - 1) >> xs;
   auto decode = [&](int I, Item& it) -> bool {
-    const int xcd = I & 7, seq = I >> 3;
+    const int xcd = I & (nx - 1), seq = I >> xs;
     const int local = seq / nCt;
     it.pixTile = xcd * tilesPerXcd + local;
     if (local >= tilesPerXcd || it.pixTile >= nPixTiles) return false;
@@ -670,14 +671,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
 template <int BN, int MT, int NW, int EPI, bool F16>
 static int launch(const ConvP& p, hipStream_t st) {
   using G = Geo<BN, MT, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    attr_set = true;
-  }
+  MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true>);
+  MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false>);
+  const DeviceShape ds = device_shape();
   const int tilesX = ceil_div(p.W, TW), tilesY = ceil_div(p.H, G::TH);
   ConvP q = p;
   q.tilesX = tilesX;
@@ -695,11 +691,12 @@ static int launch(const ConvP& p, hipStream_t st) {
   }
   const int nPixTiles = p.N * tilesX * tilesY;
   const int nCt = p.CoutPad / BN;
-  const int nItems = round_up(nPixTiles, 8) * nCt;
+  q.xcdShift = ds.xcd_shift;
+  const int nItems = round_up(nPixTiles, ds.xcds) * nCt;
   // persistent: as many workgroups as fit the chip at once
   const int per_cu = (int)((160 * 1024) / G::LDS) >= 2 && NW == 4 ? 2 : 1;
-  int grid = 256 * per_cu;
-  if (grid > nItems) grid = nItems;                    // nItems is a multiple of 8, and so is 256*per_cu
+  int grid = ds.cus / ds.xcds * ds.xcds * per_cu;      // a multiple of the XCD count, like nItems: a workgroup stays on its XCD's slice
+  if (grid > nItems) grid = nItems;
   if (q.fast) {
     MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
   } else {
@@ -726,7 +723,7 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
   // 64-row tiles exist for the 64-wide variant only (<64,4,8>: the per-MFMA LDS-read and DMA ratios of <128,4,8>)
   for (int th = 16; th <= (wide ? 32 : 64) && th <= th_max; th *= 2) {
     const int nw = wide || th > 16 ? 8 : 4;
-    const int slots = 256 * (nw == 4 ? 2 : 1);                     // <64,2,4> runs two workgroups per CU
+    const int slots = device_shape().cus * (nw == 4 ? 2 : 1);      // <64,2,4> runs two workgroups per CU
     const long tilesY = ceil_div(H, th), tilesX = ceil_div(W, TW);
     const long items = (long)N * tilesY * tilesX * nCt;
     const double grid_fill = (double)items / (double)(((items + slots - 1) / slots) * slots);

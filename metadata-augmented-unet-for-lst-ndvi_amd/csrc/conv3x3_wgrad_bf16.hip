@@ -333,11 +333,7 @@ static int launch(const WgradP& p, int nsplit, hipStream_t st) {
   constexpr size_t red = KG == 2 ? (size_t)(NW / 2) * 3 * 16 * 64 * sizeof(float) : 0;
   constexpr size_t lds = NS * stage > red ? NS * stage : red;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<BCO, KG, F16, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  MAU_LDS_ATTR(lds, &wgrad_bf16_kernel<BCO, KG, F16, NS>);
   dim3 grid(nsplit, p.CoutPad / BCO, p.CinPad / BCI);
   MAU_LAUNCH((wgrad_bf16_kernel<BCO, KG, F16, NS>), grid, dim3(BCO * 4 * KG), lds, st, p, nsplit);
   return check_launch("wgrad_bf16_kernel");
@@ -350,7 +346,7 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   const int outTiles = (CoutPad / bco) * (CinPad / 64);
   const int nTiles = N * ceil_div(H, wg2::TH) * ceil_div(W, wg2::TW);
   // one workgroup per CU is resident (LDS / accumulator budget): pick the split count whose total
-  // workgroup count fills whole rounds of 256 CUs, preferring fewer splits (less slab traffic) and
+  // workgroup count fills whole rounds of the device's CUs, preferring fewer splits (less slab traffic) and
   // at least 4 pixel tiles per workgroup (pipeline fill).
   const size_t slab_bytes = (size_t)9 * CoutPad * CinPad * sizeof(float);
   size_t cap = ((size_t)256 << 20) / slab_bytes;                 // keep the partial slabs under 256 MiB
@@ -361,10 +357,11 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   if ((size_t)smax > cap) smax = (int)cap;
   int best = 1;
   double best_score = -1.0;
+  const long cus = device_shape().cus;
   for (int s = 1; s <= smax; ++s) {                // s = workgroups along the split axis = partial slabs
     const long blocks = (long)outTiles * s;
-    const long rounds = (blocks + 255) / 256;
-    const double eff = (double)blocks / (double)(rounds * 256);
+    const long rounds = (blocks + cus - 1) / cus;
+    const double eff = (double)blocks / (double)(rounds * cus);
     const double score = eff - 0.0015 * s;
     if (score > best_score + 1e-9) {
       best_score = score;

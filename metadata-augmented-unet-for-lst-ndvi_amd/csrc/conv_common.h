@@ -45,6 +45,7 @@ struct ConvP {
   int ldy, Cout, CoutPad;
   float* slab;
   int N, H, W, tilesX, tilesY, nChunks;
+  int xcdShift;         // log2(XCDs of the device) for the XCD-contiguous work-item order (bf16 kernel, set by its launcher)
   int fast;             // (bf16 kernel, set by its launcher) every 16-channel stage lies inside one tensor: buffer-addressed loader
 };
 

@@ -394,12 +394,7 @@ int mau_lstm_bwd(const float* x, const float* w_hh, const float* gates, const fl
   auto bwd_lds = [](int HP) { return (size_t)(2 * LSTM_BS * 5 * HP + 2 * LSTM_BS + 2 * LSTM_BS * 4 * (HP + 8)) * sizeof(float); };
 #define MAU_LSTM_BWD(HP_)                                                                                                       \
   do {                                                                                                                          \
-    static bool attr_set = false;                                                                                               \
-    if (!attr_set) {                                                                                                            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<HP_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)bwd_lds(HP_));                                                                             \
-      attr_set = true;                                                                                                          \
-    }                                                                                                                           \
+    MAU_LDS_ATTR(bwd_lds(HP_), &lstm_bwd_kernel<HP_>);                                                            \
     MAU_LAUNCH(lstm_bwd_kernel<HP_>, dim3(B), dim3(4 * HP_), bwd_lds(HP_), st, x, w_hh, gates, cells, dh_last, dpre_all, dwih_p,  \
                db_p, T, H);                                                                                                     \
   } while (0)

@@ -174,10 +174,47 @@ __device__ __forceinline__ float to_f(T x) {
   return (float)x;
 }
 
+// Shape of the device the calling thread is on, queried once per device: compute units and XCDs (an XCD of gfx950 has 32
+// active CUs and its own L2; SPX mode = 8 XCDs = 256 CUs, CPX partitions = 1).  Persistent grids, split counts and the
+// XCD-contiguous work-item orders are sized from this, not from literals.  (No device: the MI355X SPX shape.)
+struct DeviceShape {
+  int cus, xcds, xcd_shift;
+};
+static inline DeviceShape device_shape() {
+  static DeviceShape cache[64];
+  static bool have[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DeviceShape{256, 8, 3};
+  if (!have[dev]) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    int x = 1, s = 0;
+    while (x < 8 && x * 2 * 32 <= cus) {
+      x *= 2;
+      ++s;
+    }
+    cache[dev] = DeviceShape{cus, x, s};
+    have[dev] = true;
+  }
+  return cache[dev];
+}
+// dynamic-LDS opt-in of a kernel, once per device (the attribute is per device, a process may drive several)
+#define MAU_LDS_ATTR(bytes, ...)                                                                                        \
+  do {                                                                                                                  \
+    static bool done_[64];                                                                                              \
+    int d_ = 0;                                                                                                         \
+    if (hipGetDevice(&d_) == hipSuccess && d_ >= 0 && d_ < 64 && !done_[d_]) {                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)(bytes));                                                                          \
+      done_[d_] = true;                                                                                                 \
+    }                                                                                                                   \
+  } while (0)
+
 // grid sizing for streaming kernels: cap at 8 blocks per CU and grid-stride the rest
 static inline int stream_grid(int64_t work_items, int block) {
   int64_t g = (work_items + block - 1) / block;
-  if (g > 256 * 8) g = 256 * 8;
+  const int64_t cap = (int64_t)device_shape().cus * 8;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }

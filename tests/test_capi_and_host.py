@@ -35,9 +35,9 @@ def test_library_exports_every_header_symbol():
     # pure host-side helpers of the ABI are callable without a GPU
     assert _lib.lib.mau_conv3x3_kc(_lib.MAU_BF16) == 16 and _lib.lib.mau_conv3x3_kc(_lib.MAU_F32) == 16
     assert _lib.lib.mau_conv3x3_packed_elems(_lib.MAU_BF16, 64, 6) == 1 * 9 * 64 * 16
-    # bf16 tile height is chosen per layer (grid fill): 32-row tiles on a full grid, 16-row tiles when the layer is small
-    # (slab rows = workgroup tiles x wave rows per workgroup)
-    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 256, 256, 64) == 32 * 8 * 16 * 8
+    # bf16 tile height is chosen per layer (grid fill): 64-row (64-wide) / 32-row (128-wide) tiles on a full grid, 16-row
+    # tiles when the layer is small (slab rows = workgroup tiles x wave rows per workgroup)
+    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 256, 256, 64) == 32 * 4 * 16 * 8
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 32, 32, 256) == 32 * 2 * 2 * 4
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 2, 16, 16, 1024) == 2 * 4
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 16, 16, 1024) == 32 * 4
