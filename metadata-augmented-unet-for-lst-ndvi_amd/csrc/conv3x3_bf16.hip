@@ -159,6 +159,69 @@ struct StageSched {
   }
 };
 
+// ---- The same stage pair on v_mfma_f32_16x16x32 (M16 variants) ----
+// Under load the chip holds a higher clock on the 16x16x32 shape than on 32x32x16 at equal cycles per FLOP
+// (MI355X_MICROARCH.md, DVFS give-back (7); timed in this kernel's own loop: +7..10 %).  K = 32 of one MFMA =
+// 16 channels of TWO taps: lanes 0-31 (k-slices 0, 1) read tap t of the step, lanes 32-63 (k-slices 2, 3) tap t'; the
+// fragment of a lane is still one 16-byte read at its own address, so the LDS image and the loader do not change.  Nine
+// taps do not pair inside one 16-channel stage, so two stages are walked together: stage A taps (0,1)(2,3)(4,5)(6,7), the
+// CROSS step (tap 8 of A | tap 0 of B) -- after the barrier that publishes B's buffer, before the one that releases A's
+// -- then stage B taps (1,2)(3,4)(5,6)(7,8): 9 steps of 32 MFMAs for 2 x 9 taps (three barriers per two stages, not two).
+// wave tile = 8 pixel rows of 16 x 4 channel tiles of 16; acc[y][n], lane l: channel column l % 16, pixels 4 * (l / 16) + r.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// In-place (vdst = srcC) by construction: through the builtin the 288 unrolled updates of a stage pair were renamed freely
+// and the 32 accumulators came back to their loop-carried registers through 128 v_mov per pair (and spills).  Consecutive
+// MFMAs of the schedule never touch the same accumulator; the epilogue reads them long after the last one.
+template <bool F16>
+__device__ __forceinline__ void mfma32k(const bf16x8& a, const bf16x8& b, f32x4v& c) {
+  if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+struct PairSched {
+  static constexpr int NS = 9, NM = NS * 32, NR = NS * 12;
+  static constexpr int B1 = 127, B2 = 159;              // barriers follow these MFMAs (end of stage A's pairs; end of the cross step)
+#ifdef MAU_CONV_M16_LEAD
+  static constexpr int LEAD = MAU_CONV_M16_LEAD, RA = MAU_CONV_M16_RA, RB = MAU_CONV_M16_RB;
+#else
+  static constexpr int LEAD = 12, RA = 6, RB = 8;
+#endif
+  struct RD { int isA, s, idx, need, last, iss, seq; };   // idx: pixel row y (A) / channel tile n (B)
+  RD rd[NR] = {};
+  int lo[NM + 1] = {};
+  int ka[NS][8] = {}, kb[NS][4] = {};
+  constexpr PairSched() {
+    int k = 0, aseq = 0, bseq = 0;
+    for (int s = 0; s < NS; ++s) {
+      const int rel = s <= 3 ? -1 : B1;                  // steps 4.. read stage B's buffer: not before the barrier after MFMA B1
+      for (int o = 0; o < 12; ++o) {                     // need order: B0 A0 B1 B2 B3 A1 .. A7
+        const bool isA = o == 1 || o >= 5;
+        const int idx = o == 0 ? 0 : o == 1 ? 0 : o <= 4 ? o - 1 : o - 4;
+        const int need = 32 * s + (isA ? 4 * idx : idx), last = 32 * s + (isA ? 4 * idx + 3 : 28 + idx);
+        int iss = need - LEAD;
+        if (iss < rel) iss = rel;
+        rd[k] = {isA ? 1 : 0, s, idx, need, last, iss, isA ? aseq++ : bseq++};
+        if (isA) ka[s][idx] = k;
+        else kb[s][idx] = k;
+        ++k;
+      }
+    }
+    int c = 0;
+    for (int M = 0; M <= NM; ++M) {
+      while (c < NR && rd[c].iss < M) ++c;
+      lo[M] = c;
+    }
+  }
+  constexpr bool ok() const {
+    for (int i = 0; i < NR; ++i) {
+      if (i > 0 && (rd[i].need < rd[i - 1].need || rd[i].iss < rd[i - 1].iss)) return false;
+      for (int j = 0; j < i; ++j)
+        if (rd[j].isA == rd[i].isA && rd[j].seq + (rd[i].isA ? RA : RB) == rd[i].seq && rd[j].last > rd[i].iss) return false;
+    }
+    return lo[NM] == NR;
+  }
+};
+inline constexpr PairSched kPairSched{};
+
 template <int MT>
 inline constexpr StageSched<MT> kStageSched{};
 
@@ -249,8 +312,9 @@ __device__ __forceinline__ void dma_issue_buf(__amdgpu_buffer_rsrc_t rs, int vof
 #endif
 }
 
-template <int BN, int MT, int NW, int EPI, bool F16, bool FAST>
+template <int BN, int MT, int NW, int EPI, bool F16, bool FAST, bool M16>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
+  static_assert(!M16 || (MT == 4 && NW == 8 && FAST), "the 16x16x32 loop: 128-pixel wave strips, buffer-addressed loader");
   using G = Geo<BN, MT, NW>;
   constexpr int WN = G::WN, WM = G::WM, TH = G::TH, HPIX = G::HPIX, HALO_Q = G::HALO_Q, HALO_BYTES = G::HALO_BYTES;
   constexpr int TOT_Q = G::TOT_Q, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE;
@@ -311,12 +375,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
     if (q < HALO_Q) {
       const int slot = q * 64 + lane;
       const int hp = slot >> 1, ph = slot & 1;
-      c = 8 * (ph ^ halo_swz(hp % HS));
+      c = 8 * (M16 ? ph : ph ^ halo_swz(hp % HS));      // (M16: the lane groups of its reads are conflict-free unswizzled)
       hp_or_row = hp < HPIX ? hp : -1;
     } else if (q < TOT_Q) {
       const int slot = (q - HALO_Q) * 64 + lane;
       const int row = slot >> 1, ph = slot & 1;
-      c = 8 * (ph ^ ((row >> 3) & 1));
+      c = 8 * (M16 ? ph : ph ^ ((row >> 3) & 1));
       hp_or_row = row;
     }
   };
@@ -423,13 +487,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
   bool stores_behind = false;      // (wave-uniform) the previous item's epilogue issued exactly its 4 * MT output stores
   while (true) {
     const int In = next_valid(I + gridDim.x, nxt);
-    f32x16 acc[MT][2];
+    f32x16 acc[M16 ? 1 : MT][2];
+    f32x4v acc16[M16 ? 8 : 1][4];
+    if constexpr (M16) {
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+      for (int a = 0; a < 8; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b) acc16[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;   // (bias-initialised accumulators make the MT = 4 variants spill 100 registers)
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;   // (bias-initialised accumulators make the MT = 4 variants spill 100 registers)
+    }
 
     // ---- K loop.  Between two stages: wait for this wave's DMAs -> raw barrier (every wave's DMAs have landed and
     // everyone is done with the buffer that is refilled next); inside a stage: issue the following stage, which may
@@ -445,6 +517,73 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
 #endif
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if constexpr (M16) {
+      using PS = PairSched;
+      static_assert(kPairSched.ok(), "pair schedule");
+      static_assert(PER_WAVE <= 7, "DMA slots of the pair schedule");
+      const bool up = lane >= 32;
+      const unsigned laneA = ((wm * 8) * HS + (lane & 15)) * ROWB + 16 * ((lane >> 4) & 1);
+      const unsigned laneB = HALO_BYTES + (wn * 64 + (lane & 15)) * ROWB + 16 * ((lane >> 4) & 1);
+      for (int chunk = 0; chunk < p.nChunks; chunk += 2) {       // (the launcher sends only even stage counts here)
+        const bool moreB = chunk + 2 < p.nChunks;
+        const int fchunkB = moreB ? chunk + 2 : 0;
+        const unsigned sA = lds0 + stage * STAGE, sB = lds0 + (stage ^ 1) * STAGE;
+        bf16x8 fa[PS::RA] = {}, fb[PS::RB] = {};
+        unsigned aAddr = 0, bAddr = 0;
+        auto issue_read = [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          constexpr PS::RD R = kPairSched.rd[k];
+          if constexpr (!R.isA && R.idx == 0) {                   // first read of step s: its two taps' addresses
+            constexpr int st = R.s;
+            constexpr int tlo = st <= 3 ? 2 * st : st == 4 ? 8 : 2 * (st - 5) + 1;
+            constexpr int thi = st <= 3 ? 2 * st + 1 : st == 4 ? 0 : 2 * (st - 5) + 2;
+            const unsigned blo = st <= 4 ? sA : sB, bhi = st <= 3 ? sA : sB;
+            aAddr = laneA + (up ? bhi + ((thi / 3) * HS + thi % 3) * ROWB : blo + ((tlo / 3) * HS + tlo % 3) * ROWB);
+            bAddr = laneB + (up ? bhi + thi * BN * ROWB : blo + tlo * BN * ROWB);
+          }
+          if constexpr (R.isA) fa[R.seq % PS::RA] = lds_read128<R.idx * HS * ROWB>(aAddr);
+          else fb[R.seq % PS::RB] = lds_read128<R.idx * 16 * ROWB>(bAddr);
+        };
+        static_for<0, kPairSched.lo[0]>([&](auto kc) { issue_read(kc); });
+        static_for<0, PS::NM>([&](auto Mc) {
+          constexpr int M = decltype(Mc)::value, st = M / 32, y = (M % 32) / 4, n = M % 4;
+          constexpr int kA = kPairSched.ka[st][y], kB = kPairSched.kb[st][n];
+          constexpr int as = kPairSched.rd[kA].seq % PS::RA, bs = kPairSched.rd[kB].seq % PS::RB;
+          if constexpr (kPairSched.rd[kA].need == M || kPairSched.rd[kB].need == M) {
+            constexpr int kmax = kA > kB ? kA : kB;
+            constexpr int allowed = kPairSched.lo[M] - (kmax + 1);
+            static_assert(allowed >= 0 && allowed <= 15, "lgkmcnt range");
+            landed<allowed>(fa[as], fb[bs]);
+          }
+          mfma32k<F16>(fa[as], fb[bs], acc16[y][n]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (M == PS::B1) {                              // stage B's buffer: every wave's DMAs have landed
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+          }
+          if constexpr (M == PS::B2) {                              // stage A's buffer: everyone is done reading it
+            __builtin_amdgcn_s_barrier();
+            if (!moreB && In >= 0) setup(nxt);
+          }
+          if constexpr (kPairSched.lo[M + 1] > kPairSched.lo[M]) {
+            static_for<kPairSched.lo[M], kPairSched.lo[M + 1]>([&](auto kc) { issue_read(kc); });
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (M < 128 && M % 14 == 10 && M / 14 < PER_WAVE) {
+            MAU_ISSUE_SLOT(M / 14, stage ^ 1, chunk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (M >= 160 && (M - 160) % 14 == 10 && (M - 160) / 14 < PER_WAVE) {
+            MAU_ISSUE_SLOT((M - 160) / 14, stage, fchunkB);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        if (moreB) {
+          wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+    } else
     for (int chunk = 0; chunk < p.nChunks; ++chunk) {
       // next stage: the following chunk of this item, or chunk 0 of the next item (cross-tile pipelining);
       // after the very last stage chunk 0 of the current item is re-fetched into the idle buffer (nobody reads it)
@@ -553,10 +692,96 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
     __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer stage^1 -> reuse it
     // wave-private staging image: 32 pixels x 64 channels bf16 (128-byte rows)
     const unsigned stg = lds0 + (stage ^ 1) * STAGE + wave * (32 * 64 * 2);
+    const bool full = cur.ty0 + TH <= p.H && cur.tx0 + TW <= p.W;     // interior tiles (the common case): mask-free, workgroup-uniform
+    const unsigned rbase = stg + (lane >> 3) * 128 + (lane & 7) * 16;   // read: pixel pass*8 + lane/8, 16-byte vector lane%8
+    const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
+    if constexpr (M16) {
+      // lane (q = lane / 16, c = lane % 16): pixels x = 4q + r of row y, channel column c of tile n; the packed rows put
+      // channels 32 (n & 1) + 2c + (n >> 1) there, so tiles (n, n + 2) of a lane are an adjacent channel pair
+      const int q4 = (lane >> 4) * 4, c16 = lane & 15;
+      const int cb = cur.co0 + wn * 64 + 2 * c16;               // + 32 n + e
+      const unsigned wb16 = stg + q4 * 128 + c16 * 4;
+      float bv[2][2], s4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, q4s[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, psc[2][2] = {}, psh[2][2] = {};
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int ch = cb + 32 * n + e;
+          bv[n][e] = (p.bias != nullptr && ch < p.Cout) ? p.bias[ch] : 0.f;
+          if (EPI == EPI_POST) {
+            psc[n][e] = ch < p.Cout ? p.post_scale[ch] : 0.f;
+            psh[n][e] = ch < p.Cout ? p.post_shift[ch] : 0.f;
+          }
+        }
+      const int xrem = p.W - cur.tx0 - q4;                       // pixel x = q4 + r is inside the image iff r < xrem
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int ybase = cur.ty0 + wm * 8 + mt * 2;
+        static_for<0, 2>([&](auto yc) {
+          constexpr int yy = decltype(yc)::value;
+          const bool yok = full || ybase + yy < p.H;
+          static_for<0, 2>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            static_for<0, 4>([&](auto rc) {
+              constexpr int r = decltype(rc)::value;
+              float v0 = acc16[mt * 2 + yy][n][r], v1 = acc16[mt * 2 + yy][n + 2][r];
+              if (p.bias != nullptr) {
+                v0 += bv[n][0];
+                v1 += bv[n][1];
+              }
+              if (EPI == EPI_POST) {
+                v0 = fmaxf(fmaf(v0, psc[n][0], psh[n][0]), 0.f);
+                v1 = fmaxf(fmaf(v1, psc[n][1], psh[n][1]), 0.f);
+              }
+              if (EPI == EPI_STATS && (full || (yok && r < xrem))) {
+                s4[n][0] += v0;
+                s4[n][1] += v1;
+                q4s[n][0] = fmaf(v0, v0, q4s[n][0]);
+                q4s[n][1] = fmaf(v1, v1, q4s[n][1]);
+              }
+              const f32x2 v = {v0, v1};
+              lds_write_b32<(yy * 16 + r) * 128 + 64 * n>(wb16, pack_lp2<F16>(v));
+            });
+          });
+        });
+        u32x4 o0 = lds_read_u128<0 * 1024>(rbase), o1 = lds_read_u128<1 * 1024>(rbase);
+        u32x4 o2 = lds_read_u128<2 * 1024>(rbase), o3 = lds_read_u128<3 * 1024>(rbase);
+        lds_land(o0, o1, o2, o3);
+        if (cv < p.ldy) {
+          const u32x4 ov[4] = {o0, o1, o2, o3};
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+            const int prow = pass * 8 + (lane >> 3);
+            const int gy = ybase + (prow >> 4), gx = cur.tx0 + (prow & 15);
+            if (full || (gy < p.H && gx < p.W))
+              __builtin_nontemporal_store(ov[pass], reinterpret_cast<u32x4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv));
+          }
+        }
+      }
+      if (EPI == EPI_STATS) {
+        float* srow = p.slab + ((size_t)cur.pixTile * WM + wm) * 2 * p.CoutPad + cb;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            s4[n][e] += __shfl_xor(s4[n][e], 16);
+            s4[n][e] += __shfl_xor(s4[n][e], 32);
+            q4s[n][e] += __shfl_xor(q4s[n][e], 16);
+            q4s[n][e] += __shfl_xor(q4s[n][e], 32);
+          }
+        if (lane < 16) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const f32x2 sv = {s4[n][0], s4[n][1]}, qv = {q4s[n][0], q4s[n][1]};
+            *reinterpret_cast<f32x2*>(srow + 32 * n) = sv;
+            *reinterpret_cast<f32x2*>(srow + 32 * n + p.CoutPad) = qv;
+          }
+        }
+      }
+    } else {
     unsigned wbase[4];                                 // write: row rowbase[g] + k, channel pair 2*i32 (one dword)
 #pragma unroll
     for (int g = 0; g < 4; ++g) wbase[g] = stg + rowbase[g] * 128 + i32 * 4;
-    const unsigned rbase = stg + (lane >> 3) * 128 + (lane & 7) * 16;   // read: pixel pass*8 + lane/8, 16-byte vector lane%8
     // lane i32, accumulator tile nt <-> output channel 2*i32 + nt of the wave's 64 (see pack_weights_kernel)
     const int cpair = cur.co0 + wn * 64 + 2 * i32;
     float bv[2];
@@ -571,9 +796,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
         psh[nt] = cpair + nt < p.Cout ? p.post_shift[cpair + nt] : 0.f;
       }
     }
-    const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
-    // interior tiles (the common case) take the mask-free path; the branch is workgroup-uniform
-    const bool full = cur.ty0 + TH <= p.H && cur.tx0 + TW <= p.W;
     int xlim[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) xlim[g] = p.W - cur.tx0 - (rowbase[g] & 15);
@@ -659,6 +881,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
         *reinterpret_cast<f32x2*>(srow + p.CoutPad) = qv;
       }
     }
+    }   // (!M16)
     if (In < 0) break;
     stores_behind = full && cur.co0 + wn * 64 + 64 <= p.ldy;     // every lane stored, 4 * MT store instructions per wave
     cur = nxt;
@@ -668,11 +891,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
 #undef MAU_ISSUE_SLOT
 }
 
+#ifdef MAU_CONV_DEV_ONE               // development aid: compile ONE instantiation (register / ISA checks in seconds, not minutes)
+template __global__ void conv3x3_bf16_kernel<MAU_CONV_DEV_ONE>(ConvP, int, int, int);
+}  // namespace v2
+}  // namespace mau
+#else
 template <int BN, int MT, int NW, int EPI, bool F16>
 static int launch(const ConvP& p, hipStream_t st) {
   using G = Geo<BN, MT, NW>;
-  MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true>);
-  MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false>);
+  MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, false>);
+  MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false, false>);
+  if constexpr (MT == 4 && NW == 8) MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>);
   const DeviceShape ds = device_shape();
   const int tilesX = ceil_div(p.W, TW), tilesY = ceil_div(p.H, G::TH);
   ConvP q = p;
@@ -697,10 +926,21 @@ static int launch(const ConvP& p, hipStream_t st) {
   const int per_cu = (int)((160 * 1024) / G::LDS) >= 2 && NW == 4 ? 2 : 1;
   int grid = ds.cus / ds.xcds * ds.xcds * per_cu;      // a multiple of the XCD count, like nItems: a workgroup stays on its XCD's slice
   if (grid > nItems) grid = nItems;
-  if (q.fast) {
-    MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+  // the 16x16x32 loop walks stages in pairs: big-tile variants, buffer-addressed loader, an even number of stages
+  // (MAU_CONV_M16=0: the 32x32x16 loop everywhere, for same-box A/B timing)
+  static const bool m16 = getenv("MAU_CONV_M16") == nullptr || atoi(getenv("MAU_CONV_M16")) != 0;
+  bool done = false;
+  if constexpr (MT == 4 && NW == 8) {
+    if (m16 && q.fast && q.nChunks % 2 == 0) {
+      MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+      done = true;
+    }
+  }
+  if (done) {
+  } else if (q.fast) {
+    MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, false>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
   } else {
-    MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+    MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false, false>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
   }
   return check_launch("conv3x3_bf16_kernel");
 }
@@ -772,3 +1012,4 @@ int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
 }
 
 }  // namespace mau
+#endif
