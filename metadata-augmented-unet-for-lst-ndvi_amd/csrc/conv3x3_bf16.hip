@@ -42,58 +42,18 @@ __device__ __forceinline__ int w_off(int row, int half) { return row * ROWB + 16
 // the key ignores the halo row, a tap's (dy, mt) row shift is a pure immediate offset of the read address.
 __device__ __forceinline__ int halo_swz(int hx) { return (hx >> 3) & 1; }
 
-template <int TAP, int BN, int MT>
-__device__ __forceinline__ void fetch_tap(bf16x8 (&fb)[2], bf16x8 (&fa)[MT], unsigned b0a, unsigned b1a, const unsigned (&aa)[3]) {
-  constexpr int dy = TAP / 3, dx = TAP % 3;
-#ifdef MAU_CONV_ABL_NOREAD          // timing-only ablation: fragments are whatever the registers hold
-  return;
-#endif
-  fb[0] = lds_read128<TAP * BN * ROWB>(b0a);
-  fb[1] = lds_read128<TAP * BN * ROWB>(b1a);
-  fa[0] = lds_read128<(0 * 2 + dy) * HS * ROWB>(aa[dx]);
-  fa[1] = lds_read128<(1 * 2 + dy) * HS * ROWB>(aa[dx]);
-  if constexpr (MT == 4) {
-    fa[2] = lds_read128<(2 * 2 + dy) * HS * ROWB>(aa[dx]);
-    fa[3] = lds_read128<(3 * 2 + dy) * HS * ROWB>(aa[dx]);
-  }
-}
-// one fragment of a tap: I = 0, 1 -> the two weight fragments, I >= 2 -> pixel fragment I - 2
-template <int TAP, int BN, int MT, int I>
-__device__ __forceinline__ void fetch_piece(bf16x8 (&fb)[2], bf16x8 (&fa)[MT], unsigned b0a, unsigned b1a, const unsigned (&aa)[3]) {
-  constexpr int dy = TAP / 3, dx = TAP % 3;
-#ifdef MAU_CONV_ABL_NOREAD
-  return;
-#endif
-  if constexpr (I == 0) fb[0] = lds_read128<TAP * BN * ROWB>(b0a);
-  else if constexpr (I == 1) fb[1] = lds_read128<TAP * BN * ROWB>(b1a);
-  else fa[I - 2] = lds_read128<((I - 2) * 2 + dy) * HS * ROWB>(aa[dx]);
-}
-// Fragment r of a tap in NEED order of the MFMA sequence (mt, nt) = (0,0), (0,1), (1,0), ...: weight 0, pixel 0, weight 1,
-// pixel 1, pixel 2, ...  DS operations return in issue order, so "fragment r has landed" is a counted lgkmcnt.
-template <int TAP, int BN, int MT, int R>
-__device__ __forceinline__ void fetch_need(bf16x8 (&fb)[2], bf16x8 (&fa)[MT], unsigned b0a, unsigned b1a, const unsigned (&aa)[3]) {
-  fetch_piece<TAP, BN, MT, (R == 0 ? 0 : R == 1 ? 2 : R == 2 ? 1 : R)>(fb, fa, b0a, b1a, aa);
-}
+// wait until at most N of this wave's LDS operations are outstanding; a, b: the fragments that have landed by then
 template <int N>
 __device__ __forceinline__ void landed(bf16x8& a, bf16x8& b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
-// wait until at most N of this wave's LDS operations are outstanding; the fragments of the tap about to be multiplied
-template <int N, int MT>
-__device__ __forceinline__ void land(bf16x8 (&fb)[2], bf16x8 (&fa)[MT]) {
-  static_assert(MT == 2 || MT == 4, "fragment count");
-  if constexpr (MT == 2)
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fa[0]), "+v"(fa[1]) : "n"(N));
-  else
-    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]) : "n"(N));
-}
-
 // ---- The multiply schedule of one stage (16 input channels x 9 taps) of a wave ----
 // Taps are walked dx-major.  For one dx the pixel fragment of halo ROW PAIR r (rows r, r + 1 of the wave's strip, shifted by
 // dx) is the operand of every (tile mt, dy) with 2 * mt + dy = r -- up to two tiles -- so it is read ONCE: 2 * MT + 1
-// pixel fragments per dx instead of 3 * MT, 9 instead of 12 for MT = 4 (LDS reads are what the kernel's power goes into,
-// after the MFMAs: see DESIGN.md, "the clock is the bound").  A fragment read is issued LEAD MFMAs before its first use, in
-// need order; DS operations return in order, so "fragment k has landed" is a counted lgkmcnt.
+// pixel fragments per dx instead of 3 * MT, 9 instead of 12 for MT = 4: 45 fragment reads per stage instead of 54.  (Measured
+// against the tap-major loop with 54: no difference in time -- the kernel is clock-bound, DESIGN.md "the clock is the
+// bound", and the clock did not move; kept for the LDS bytes.)  A fragment read is issued LEAD MFMAs before its first
+// use, in need order; DS operations return in order, so "fragment k has landed" is a counted lgkmcnt.
 template <int MT>
 struct StageSched {
   static constexpr int NG = 3, ROWS = 2 * MT + 1;
@@ -604,39 +564,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
 #else
       constexpr int DPT = PER_WAVE > 9 ? 2 : 1;
 #endif
-      constexpr int DMA_AT = 2 * MT - 2;
-#ifdef MAU_CONV_TAP_LOOP
-      // (the previous loop, kept for A/B timing: tap-major, every tap reads its own 2 + MT fragments)
-      bf16x8 fb[2][2] = {}, fa[2][MT] = {};
-      static_for<0, 2 + MT>([&](auto rc) { fetch_need<0, BN, MT, decltype(rc)::value>(fb[0], fa[0], b0a, b1a, aa); });
-#define MAU_TAP(T)                                                                    \
-  {                                                                                   \
-    constexpr int cs = (T)&1, NX = (T) < 8 ? (T) + 1 : 0;                             \
-    static_for<0, 2 * MT>([&](auto ic) {                                              \
-      constexpr int i = decltype(ic)::value, mt = i >> 1, nt = i & 1;                 \
-      constexpr int need = i == 0 ? 1 : i == 1 ? 2 : (i & 1) ? -1 : 2 + (i >> 1);     \
-      if constexpr (need >= 0) {                                                      \
-        constexpr int ahead = (T) < 8 ? (i < 2 + MT ? i : 2 + MT) : 0;                \
-        landed<(1 + MT - need) + ahead>(fa[cs][mt], fb[cs][nt]);                      \
-      }                                                                               \
-      acc[mt][nt] = mfma16<F16>(fa[cs][mt], fb[cs][nt], acc[mt][nt]);                 \
-      __builtin_amdgcn_sched_barrier(0);                                              \
-      if constexpr ((T) < 8 && i < 2 + MT) {                                          \
-        fetch_need<NX, BN, MT, i>(fb[cs ^ 1], fa[cs ^ 1], b0a, b1a, aa);              \
-        __builtin_amdgcn_sched_barrier(0);                                            \
-      }                                                                               \
-      if constexpr (i == DMA_AT && (T) * DPT < PER_WAVE && !ABL_NODMA) {              \
-        static_for<0, DPT>([&](auto rc) {                                             \
-          constexpr int J = (T) * DPT + decltype(rc)::value;                          \
-          if constexpr (J < PER_WAVE) MAU_ISSUE_SLOT(J, stage ^ 1, fchunk);           \
-        });                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                            \
-      }                                                                               \
-    });                                                                               \
-  }
-      MAU_TAP(0) MAU_TAP(1) MAU_TAP(2) MAU_TAP(3) MAU_TAP(4) MAU_TAP(5) MAU_TAP(6) MAU_TAP(7) MAU_TAP(8)
-#undef MAU_TAP
-#else
       // The stage's NM MFMAs in StageSched order; between two MFMAs of the wave (an MFMA holds the vector issue port for
       // 8 of its 32 cycles) go the fragment reads that are LEAD MFMAs from their first use and, every NM / 9 MFMAs, one
       // wave-DMA of the following stage (a wave-DMA costs its issuing wave 60-185 cycles, MI355X_MICROARCH.md: in a burst
@@ -680,7 +607,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
           __builtin_amdgcn_sched_barrier(0);
         }
       });
-#endif
       stage ^= 1;
       if (more) {                                      // (after the last stage the epilogue's barrier takes this place)
         wait_vmcnt<0>();

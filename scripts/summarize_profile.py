@@ -15,7 +15,13 @@ total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    fs = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    if not fs:
+        continue
+    f = fs[-1]                      # (a re-profiled tag keeps older passes next to the new one: the newest pass only)
     for r in csv.DictReader(open(f)):
         k, c = r["Kernel_Name"], r["Counter_Name"]
         agg[k][c] += float(r["Counter_Value"])

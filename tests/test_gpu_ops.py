@@ -4,6 +4,8 @@ fixtures generated from the reference and against the CPU oracle on seeded input
 Tolerances: fp32 parity mode <= 1e-3 relative (north star; measured ~1e-6..1e-5);
 bf16 throughput mode has its own looser, documented bound.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
