@@ -272,7 +272,7 @@ def main():
     achieved = conv["total_flop"] / (conv["total_ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
-                "kernel": "conv3x3_igemm_kernel (forward + data-gradient launches)",
+                "kernel": "conv3x3_bf16_kernel (forward + data-gradient launches)",
                 "launches": conv["launches"], "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
                 "flop_per_launch_avg": conv["total_flop"] / conv["launches"],
                 "share_of_step_time": round(conv["total_ms"] / (elapsed * 1e3), 4),

@@ -3,6 +3,7 @@
 // All HBM-streaming, one 8-channel vector (16 B bf16 / 32 B f32) per lane.
 // Reference: src/model.py:57,218 (pool), :219,243-246,111-121 (upsample / _upsample_match),
 // :279-282,136-177 (torch.cat on channels), :248-259,98-108 (embedding broadcast).
+#include <stdlib.h>
 #include "mau_common.h"
 
 namespace mau {
@@ -181,6 +182,54 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ s
   store8<T>(dst + (((size_t)n * H + yo) * W + xo) * lddst + choff + c, o);
 }
 
+// Upsampling (scale <= 1 both ways: every decoder resize of the models) by SOURCE CELL: thread = (source pixel (ys, xs), 8
+// channels) loads the cell's four corners once and writes every destination pixel whose (y0, x0) is that cell -- 2x2 of
+// them at scale 1/2, never more than 3x3 -- with exactly resize_fwd_kernel's coordinates and arithmetic (bit-identical).
+// 4 loads per ~4 stores instead of 4 per 1, a quarter of the workgroups: resize_fwd_kernel ran at 3.1-3.6 TB/s of its own
+// traffic where a plain fill of the destination reaches 6.9 (scripts/write_bw.py) -- it was bound by its one-output
+// threads, not by the write stream.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_fwd_cell_kernel(const T* __restrict__ src, int ldsrc, int h, int w, T* __restrict__ dst,
+                                                              int lddst, int choff, int H, int W, int C8) {
+  const int nv = C8 >> 3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= w * nv) return;
+  const int xs = idx / nv, c = (idx - xs * nv) * 8;
+  const int ys = blockIdx.y, n = blockIdx.z;
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  const int ys1 = ys + (ys < h - 1 ? 1 : 0), xs1 = xs + (xs < w - 1 ? 1 : 0);
+  const T* b = src + (size_t)n * h * w * ldsrc + c;
+  const F8 v00 = load8<T>(b + ((size_t)ys * w + xs) * ldsrc), v01 = load8<T>(b + ((size_t)ys * w + xs1) * ldsrc);
+  const F8 v10 = load8<T>(b + ((size_t)ys1 * w + xs) * ldsrc), v11 = load8<T>(b + ((size_t)ys1 * w + xs1) * ldsrc);
+  // destination rows / columns whose source index can be this cell (loose bounds, exact test below)
+  int ja = 0, jb = H - 1, ka = 0, kb = W - 1;
+  if (sy > 0.f) {
+    ja = max(0, (int)floorf((float)ys / sy) - 1);
+    jb = min(H - 1, (int)ceilf(((float)ys + 1.f) / sy) + 1);
+  }
+  if (sx > 0.f) {
+    ka = max(0, (int)floorf((float)xs / sx) - 1);
+    kb = min(W - 1, (int)ceilf(((float)xs + 1.f) / sx) + 1);
+  }
+  for (int j = ja; j <= jb; ++j) {
+    int y0, y1;
+    float ly0, ly1;
+    ac_src(sy, j, h, y0, y1, ly0, ly1);
+    if (y0 != ys) continue;
+    for (int k = ka; k <= kb; ++k) {
+      int x0, x1;
+      float lx0, lx1;
+      ac_src(sx, k, w, x0, x1, lx0, lx1);
+      if (x0 != xs) continue;
+      F8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o.v[e] = ly0 * (lx0 * v00.v[e] + lx1 * v01.v[e]) + ly1 * (lx0 * v10.v[e] + lx1 * v11.v[e]);
+      store8<T>(dst + (((size_t)n * H + j) * W + k) * lddst + choff + c, o);
+    }
+  }
+}
+
 // adjoint in gather form: every source pixel sums the destination pixels that read it, with the
 // same (i0, i1, l0, l1) arithmetic as the forward pass.  grid = (x-chunks of the source row, source rows, images)
 template <typename T>
@@ -235,6 +284,9 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
 // ---- adjoint of an upsampling (scale <= 1 in both directions: every decoder resize of the models) ----------------------
 // (A forward kernel with a 2x2 block of destination pixels per thread -- 9 loads for 4 outputs instead of 16 -- measured
 //  7 % SLOWER than resize_fwd_kernel: the forward is bound by its 4x larger write stream, not by its loads.)
+// (Also measured and dropped: an LDS-tiled adjoint -- 16x8 source pixels x 4 channel vectors per workgroup, the destination
+//  region and the per-row / per-column (index, weight) tables staged in LDS once -- ran 1.6x SLOWER than this kernel at
+//  C = 128..512 (64-byte pieces of every pixel row per workgroup), equal at C = 1024.)
 // Backward: one thread = a 2x2 block of SOURCE pixels x 8 channels; every destination pixel of the union window is loaded
 // once and feeds up to four accumulators (9 loads per output instead of 16 at scale 1/2); per source pixel the
 // accumulation order (destination rows, then columns) and the weights are those of resize_bwd_kernel.
@@ -499,6 +551,12 @@ int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst,
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldsrc % 8 == 0 && lddst % 8 == 0 && choff % 8 == 0 && ldsrc >= C8 && lddst >= choff + C8, "resize_bilinear_fwd: bad ld/choff");
   MAU_REQUIRE(H <= 65535 && N <= 65535, "resize_bilinear_fwd: H and N must fit a grid dimension");
+  static const bool no_cell = getenv("MAU_RESIZE_NO_CELL") != nullptr;              // (A/B timing)
+  if (h <= H && w <= W && h <= 65535 && !no_cell) {                                // upsampling: one thread per source cell
+    dim3 gridc(ceil_div(w * (C8 / 8), 256), h, N);
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_fwd_cell_kernel<T>, gridc, dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, H, W, C8));
+    return check_launch("resize_fwd_cell_kernel");
+  }
   dim3 grid(ceil_div(W * (C8 / 8), 256), H, N);
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, H, W, C8));
   return check_launch("resize_fwd_kernel");
