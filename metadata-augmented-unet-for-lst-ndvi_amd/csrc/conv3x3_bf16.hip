@@ -904,6 +904,28 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
 }
 }  // namespace v2
 
+// ---- translation units ----
+// The kernel has 72 instantiations (5 tile variants x 2 loaders + 2 stage-pair variants, x 3 epilogues x 2 operand types) of
+// 4-5 s each: one (epilogue, operand type) slice per translation unit (conv3x3_bf16_e<EPI>_<type>.hip define MAU_CONV_TU_EPI /
+// MAU_CONV_TU_F16 and include this file), built in parallel; this file alone carries the variant choice and the dispatcher.
+#define MAU_CONV_TU_NAME2(e, f) launch_conv_bf16_tu_e##e##_f##f
+#define MAU_CONV_TU_NAME(e, f) MAU_CONV_TU_NAME2(e, f)
+#ifdef MAU_CONV_TU_EPI
+int MAU_CONV_TU_NAME(MAU_CONV_TU_EPI, MAU_CONV_TU_F16)(const ConvP& p, int th, hipStream_t st) {
+  constexpr int E = MAU_CONV_TU_EPI;
+  constexpr bool F = MAU_CONV_TU_F16 != 0;
+  if (p.CoutPad % 128 == 0) return th == 32 ? v2::launch<128, 4, 8, E, F>(p, st) : v2::launch<128, 2, 8, E, F>(p, st);
+  if (th == 64) return v2::launch<64, 4, 8, E, F>(p, st);
+  return th == 32 ? v2::launch<64, 2, 8, E, F>(p, st) : v2::launch<64, 2, 4, E, F>(p, st);
+}
+#else
+int launch_conv_bf16_tu_e0_f0(const ConvP&, int, hipStream_t);
+int launch_conv_bf16_tu_e1_f0(const ConvP&, int, hipStream_t);
+int launch_conv_bf16_tu_e2_f0(const ConvP&, int, hipStream_t);
+int launch_conv_bf16_tu_e0_f1(const ConvP&, int, hipStream_t);
+int launch_conv_bf16_tu_e1_f1(const ConvP&, int, hipStream_t);
+int launch_conv_bf16_tu_e2_f1(const ConvP&, int, hipStream_t);
+
 // rows of the BatchNorm partial-sum slab: one per (pixel tile, wave row of the workgroup)
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   const int CoutPad = round_up(Cout, 64);
@@ -915,27 +937,18 @@ int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   return wm * N * ceil_div(H, th) * ceil_div(W, v2::TW);
 }
 
-template <int BN, int MT, int NW, bool F16>
-static int launch_epi2(const ConvP& p, hipStream_t st) {
-  if (p.post_scale != nullptr) return v2::launch<BN, MT, NW, v2::EPI_POST, F16>(p, st);      // (a post-affine launch carries no slab)
-  if (p.slab != nullptr) return v2::launch<BN, MT, NW, v2::EPI_STATS, F16>(p, st);
-  return v2::launch<BN, MT, NW, v2::EPI_PLAIN, F16>(p, st);
-}
-template <int BN, int MT, int NW>
-static int launch_epi(const ConvP& p, bool f16, hipStream_t st) {
-  return f16 ? launch_epi2<BN, MT, NW, true>(p, st) : launch_epi2<BN, MT, NW, false>(p, st);
-}
-
 int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
   if (p.post_scale != nullptr && p.slab != nullptr) {
     set_error("conv3x3_fwd: post_scale/post_shift and the statistics slab are mutually exclusive");
     return MAU_ERR_ARG;
   }
-  const v2::Variant v = v2::pick_variant(p.CoutPad, p.N, p.H, p.W);
-  if (p.CoutPad % 128 == 0) return v.th == 32 ? launch_epi<128, 4, 8>(p, f16, st) : launch_epi<128, 2, 8>(p, f16, st);
-  if (v.th == 64) return launch_epi<64, 4, 8>(p, f16, st);
-  return v.th == 32 ? launch_epi<64, 2, 8>(p, f16, st) : launch_epi<64, 2, 4>(p, f16, st);
+  static_assert(v2::EPI_PLAIN == 0 && v2::EPI_STATS == 1 && v2::EPI_POST == 2, "translation-unit names");
+  const int th = v2::pick_variant(p.CoutPad, p.N, p.H, p.W).th;
+  if (p.post_scale != nullptr) return f16 ? launch_conv_bf16_tu_e2_f1(p, th, st) : launch_conv_bf16_tu_e2_f0(p, th, st);   // (a post-affine launch carries no slab)
+  if (p.slab != nullptr) return f16 ? launch_conv_bf16_tu_e1_f1(p, th, st) : launch_conv_bf16_tu_e1_f0(p, th, st);
+  return f16 ? launch_conv_bf16_tu_e0_f1(p, th, st) : launch_conv_bf16_tu_e0_f0(p, th, st);
 }
+#endif
 
 }  // namespace mau
 #endif
