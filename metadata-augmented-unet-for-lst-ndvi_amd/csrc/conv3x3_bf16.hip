@@ -357,6 +357,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
                                      //  body the general loader's hoisted 64-bit terms spilled across the K loop of <64,4,8>)
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.N * p.H * p.W * p.ldx * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x1), 0, p.N * p.H * p.W * p.ldx1 * 2, 0x00020000);
+  // (the broadcast embedding: base = image 0's vector, the scalar offset picks the image and the stage's channels; a lane's
+  //  offset is just its 16-byte half, or -1 outside the image -- the broadcast map is zero in the padding ring)
+  const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.emb_lp), 0, p.N * p.E * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.nChunks * 9 * p.CoutPad * KC * 2, 0x00020000);
   // the kernel arguments the loader needs, as plain scalars (the lambdas below must not keep the argument struct alive in memory)
   const unsigned long long xa = (unsigned long long)p.x, x1a = (unsigned long long)p.x1, wa = (unsigned long long)p.w;
@@ -366,8 +369,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
   const unsigned ld0v = (unsigned)p.ldx, ld1v = (unsigned)p.ldx1;
   const int lim0v = (p.C1 == 0 && p.E == 0) ? p.ldx : p.C0, lim1v = p.E == 0 ? p.C0 + p.ldx1 : p.C0 + p.C1;
   unsigned long long embn_a = 0;
+  int embn_off = 0;                 // byte offset of the loaded item's image inside the embedding matrix
   auto setup = [&](const Item& it) {
     embn_a = emb_a + 2ull * (unsigned long long)((long long)it.n * Ev);
+    embn_off = 2 * it.n * Ev;
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
       const int q = wave + j * NW;
@@ -409,7 +414,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
       dma_issue_buf(rs_w, off32[(J)], (CHUNK_) * w_stage_bytes32, dst_);                                              \
     } else if constexpr (FAST) {                                                                                       \
       if constexpr ((J) < HJ) {                                                                                        \
-        if (hasC1 && c0_ >= C0v) dma_issue_buf(rs_x1, off1[(J) < HJ ? (J) : 0], 2 * (c0_ - C0v), dst_);                \
+        if (c0_ >= Ctot) dma_issue_buf(rs_e, off32[(J)] < 0 ? -1 : (off32[(J)] & 16), embn_off + 2 * (c0_ - Ctot), dst_); \
+        else if (hasC1 && c0_ >= C0v) dma_issue_buf(rs_x1, off1[(J) < HJ ? (J) : 0], 2 * (c0_ - C0v), dst_);           \
         else dma_issue_buf(rs_x, off32[(J)], 2 * c0_, dst_);                                                          \
       }                                                                                                                \
     } else if constexpr ((J) < HJ) {                                                                                   \
@@ -836,10 +842,13 @@ static int launch(const ConvP& p, hipStream_t st) {
   q.nChunks = ceil_div(p.C0 + p.C1 + p.E, KC);
   // buffer-addressed halo loads: every 16-channel stage inside one tensor's (zero-padded) pixel row, 31-bit byte offsets
   const long long px = (long long)p.N * p.H * p.W;
+  // (with a broadcast embedding behind the tensors: the tensors end on a stage boundary and the embedding fills whole stages;
+  //  the lane offset of an embedding stage is derived from the source-0 offset: its 16-byte-half bit needs 2 * ldx % 32 == 0)
+  const bool emb_ok = p.E == 0 || (p.emb_lp != nullptr && p.E % KC == 0 && (p.C0 + p.C1) % KC == 0 && p.ldx % KC == 0);
   const bool one = p.C1 == 0 && p.ldx % KC == 0 && round_up(p.C0, KC) <= p.ldx;
   const bool two = p.C1 > 0 && p.C0 % KC == 0 && p.C0 <= p.ldx && round_up(p.C1, KC) <= p.ldx1;
   static const bool no_buf = getenv("MAU_CONV_GENERAL_LOADER") != nullptr;      // A/B: the 64-bit-address loader for every layer
-  q.fast = !no_buf && p.E == 0 && (one || two) && px * p.ldx * 2 < (1ll << 31) && px * p.ldx1 * 2 < (1ll << 31) ? 1 : 0;
+  q.fast = !no_buf && emb_ok && (one || two) && px * p.ldx * 2 < (1ll << 31) && px * p.ldx1 * 2 < (1ll << 31) ? 1 : 0;
   if ((long long)q.nChunks * 9 * p.CoutPad * KC * 2 >= (1ll << 31)) {
     set_error("conv3x3_fwd: packed weights beyond 2 GiB");
     return MAU_ERR_ARG;
