@@ -150,12 +150,25 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 // l1 = src - i0; l0 = 1 - l1.
 __device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 __device__ __forceinline__ void ac_src(float scale, int dst, int in, int& i0, int& i1, float& l0, float& l1) {
+  // (no FMA contraction: ATen rounds the product before subtracting the index; contracted, l1 = fma(scale, dst, -i0) differs by
+  //  up to an ulp of the SOURCE COORDINATE (1e-5 at 256 pixels), and differently in every kernel the compiler inlines this into)
+#pragma clang fp contract(off)
   const float s = scale * (float)dst;
   i0 = (int)s;
   if (i0 > in - 1) i0 = in - 1;
   i1 = i0 + (i0 < in - 1 ? 1 : 0);
   l1 = s - (float)i0;
   l0 = 1.f - l1;
+}
+
+// one interpolated value, every operation rounded on its own (no FMA contraction): both forward kernels below must give
+// the same bits for the same destination pixel -- left to the compiler, the loop-carried form in resize_fwd_cell_kernel
+// contracted differently from resize_fwd_kernel (1 ulp; enough to move a cancellation-heavy full-size gradient by 3e-3)
+__device__ __forceinline__ float lerp4(float ly0, float ly1, float lx0, float lx1, float v00, float v01, float v10, float v11) {
+#pragma clang fp contract(off)
+  const float top = lx0 * v00 + lx1 * v01;
+  const float bot = lx0 * v10 + lx1 * v11;
+  return ly0 * top + ly1 * bot;
 }
 
 // grid = (x-chunks of the destination row, destination rows, images); the row's (y0, y1, ly) are block-uniform
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ s
   F8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    o.v[j] = ly0 * (lx0 * v00.v[j] + lx1 * v01.v[j]) + ly1 * (lx0 * v10.v[j] + lx1 * v11.v[j]);
+    o.v[j] = lerp4(ly0, ly1, lx0, lx1, v00.v[j], v01.v[j], v10.v[j], v11.v[j]);
   store8<T>(dst + (((size_t)n * H + yo) * W + xo) * lddst + choff + c, o);
 }
 
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(256) void resize_fwd_cell_kernel(const T* __restric
       F8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        o.v[e] = ly0 * (lx0 * v00.v[e] + lx1 * v01.v[e]) + ly1 * (lx0 * v10.v[e] + lx1 * v11.v[e]);
+        o.v[e] = lerp4(ly0, ly1, lx0, lx1, v00.v[e], v01.v[e], v10.v[e], v11.v[e]);
       store8<T>(dst + (((size_t)n * H + j) * W + k) * lddst + choff + c, o);
     }
   }

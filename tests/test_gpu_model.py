@@ -137,7 +137,11 @@ def test_full_size_known_answer_fp32(mau):
         if k.endswith(".conv1.bias") or k.endswith(".conv2.bias"):
             continue
         got = float(params[k].grad.double().norm())
-        assert abs(got - ref_norm) <= 2e-3 * ref_norm + 1e-9, (k, got, ref_norm)
+        # 2e-3 of the parameter's own norm, plus 1e-6 of the WHOLE gradient's length: a parameter whose gradient is 2e-4 of the
+        # total (the metadata MLP's first layer: 4.7e-4 of 2.4) is a cancellation-heavy sum over 131k bottleneck pixels, and its
+        # norm moves by 3e-3 of itself (5e-7 of the total) with the rounding of the upsample's source coordinate alone --
+        # measured when ac_src stopped being FMA-contracted (csrc/spatial.hip), i.e. became ATen's arithmetic.
+        assert abs(got - ref_norm) <= 2e-3 * ref_norm + 1e-6 * s["grad_norm"], (k, got, ref_norm)
 
 
 @pytest.mark.parametrize("model_type,B", [("unet", 2), ("unet++", 1)])
