@@ -55,31 +55,35 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int swz128(int row) { return ((row >> 1) & 1) << 2; }   // 128-byte rows
 __device__ __forceinline__ int swz256(int row) { return (row & 3) << 2; }          // 256-byte rows
 
-// one k16 operand fragment = two transposed 8-byte reads (k 0..3 | 4..7 of the lane half's 8 pixels)
+// one k16 operand fragment = two transposed 8-byte reads (k 0..3 | 4..7 of the lane half's 8 pixels), joined into the
+// MFMA's 4-register operand AT THE READ: joined later (after the counted wait had taken the two halves as separate
+// in/out operands) the halves lived in unrelated register pairs and every fragment cost 2-4 v_mov -- 97 copies per stage
+// next to 72 MFMAs, in a kernel whose clock falls with every vector instruction.
 struct Frag {
-  u32x2 lo, hi;
+  u32x4 v;
 };
 template <int OFF, int HI>
 __device__ __forceinline__ void tr_read(Frag& f, unsigned addr) {
   static_assert(OFF >= 0 && OFF + HI < 65536, "ds offset field");
+  u32x2 lo, hi;
   asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-               : "=v"(f.lo), "=v"(f.hi)
+               : "=v"(lo), "=v"(hi)
                : "v"(addr), "n"(OFF), "n"(OFF + HI));
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
 // wait until at most N of this wave's LDS operations are outstanding; re-defines the fragments about to be
 // consumed so that their MFMAs cannot be scheduled above the wait
 template <int N>
 __device__ __forceinline__ void land(Frag& a, Frag& b) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi) : "n"(N));
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.v), "+v"(b.v) : "n"(N));
 }
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma_frag(const Frag& a, const Frag& b, f32x16 c) {
-  const u32x4 av = __builtin_shufflevector(a.lo, a.hi, 0, 1, 2, 3), bv = __builtin_shufflevector(b.lo, b.hi, 0, 1, 2, 3);
   if constexpr (F16) {
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v), __builtin_bit_cast(f16x8, b.v), c, 0, 0, 0);
   } else {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
   }
 }
 
