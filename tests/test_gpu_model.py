@@ -252,8 +252,13 @@ def test_multi_step_training_tracks_oracle(mau, opt_kw):
         opt.zero_grad()
         ref_losses.append(float(loss_ref))
         losses.append(float(loss))
+    # Step 0 runs on identical weights: forward parity (1e-5).  From then on two fp32 implementations drift apart through
+    # AdamW (m / sqrt(v) turns rounding noise in near-zero gradient entries into lr-sized steps): 3.7e-3 at step 3 was measured
+    # after nothing but the rounding of the upsample's source coordinate changed.  Stale packed weights -- what this test is
+    # for -- leave the loss at the initial model's level instead: 8 % off by step 3 (1.145 -> 1.056 in the oracle).
     for k, (a, b) in enumerate(zip(losses, ref_losses)):
-        assert abs(a - b) < 2e-3 * abs(b), (k, losses, ref_losses)
+        assert abs(a - b) < (1e-5 if k == 0 else 1e-2) * abs(b), (k, losses, ref_losses)
+    assert ref_losses[3] < 0.95 * ref_losses[0]          # (the margin the 1e-2 band relies on)
     # with stale weights the eval output after training would equal the initial model's: check it moved with the oracle
     net.eval()
     with torch.no_grad():
