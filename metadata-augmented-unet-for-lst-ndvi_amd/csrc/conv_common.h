@@ -16,15 +16,6 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 // 16-bit operand fragments travel as raw 128-bit registers (typed bf16x8); F16 selects how the matrix core reads them
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
-#ifdef MAU_ABL_MFMA_16X16X32         // timing-only: the same flops as two 16x16x32 MFMAs (garbage results)
-  typedef float f32x4_ __attribute__((ext_vector_type(4)));
-  f32x4_ c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-  c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
-  c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
-  c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
-  c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
-  return c;
-#endif
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }

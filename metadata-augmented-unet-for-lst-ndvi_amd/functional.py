@@ -94,6 +94,24 @@ _DT = {MAU_F32: torch.float32, MAU_BF16: torch.bfloat16, MAU_F16: torch.float16}
 _GENERATION = [0]
 
 
+_ZERO_ARENA = {"gen": -1, "buf": None, "cur": 0}
+
+
+def _zero_bias_grad(n, dev):
+    """A zero vector for an identically-zero bias gradient: a slice of one zero-filled arena per optimizer step (one fill
+    kernel per step instead of one per layer: 18 launches of ~4 us each in the U-Net).  A region is handed out once and never
+    again, so the slices behave like independent tensors (they may become ``param.grad`` and be scaled or accumulated into)."""
+    z = _ZERO_ARENA
+    need = (n + 63) // 64 * 64
+    if z["gen"] != _GENERATION[0] or z["buf"] is None or z["buf"].device != dev or z["cur"] + need > z["buf"].numel():
+        z["buf"] = torch.zeros(max(8192, need), dtype=torch.float32, device=dev)
+        z["cur"] = 0
+        z["gen"] = _GENERATION[0]
+    out = z["buf"][z["cur"]:z["cur"] + n]
+    z["cur"] += need
+    return out
+
+
 def mark_params_updated(*_args, **_kwargs):
     """Invalidate every cached weight pack.  Registered as a GLOBAL optimizer-step post hook (below), so any
     ``torch.optim`` step -- including the fused AdamW kernel, which updates parameters in place WITHOUT bumping
@@ -424,7 +442,7 @@ class ConvBNReLU(torch.autograd.Function):
         if needs[4]:
             if st.training:
                 # conv bias followed by train-mode BN has an identically zero gradient (the batch mean absorbs it)
-                dbias = torch.zeros(Cout, **f32)
+                dbias = _zero_bias_grad(Cout, dev)
             else:
                 # eval-mode BN is the fixed affine map z = scale*y + shift: d/dbias = sum(dy) = scale * sum(dz)
                 dbias = scale * dbeta
