@@ -297,6 +297,8 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
 // ---- adjoint of an upsampling (scale <= 1 in both directions: every decoder resize of the models) ----------------------
 // (A forward kernel with a 2x2 block of destination pixels per thread -- 9 loads for 4 outputs instead of 16 -- measured
 //  7 % SLOWER than resize_fwd_kernel: the forward is bound by its 4x larger write stream, not by its loads.)
+// (Measured on top of the row-wise loads below: also skipping the zero-weight ROWS of an accumulator +9 % time -- kept only the
+//  column test.)
 // (Also measured and dropped: an LDS-tiled adjoint -- 16x8 source pixels x 4 channel vectors per workgroup, the destination
 //  region and the per-row / per-column (index, weight) tables staged in LDS once -- ran 1.6x SLOWER than this kernel at
 //  C = 128..512 (64-byte pieces of every pixel row per workgroup), equal at C = 1024.)
@@ -326,6 +328,69 @@ __global__ __launch_bounds__(256) void resize_bwd2_kernel(const T* __restrict__ 
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int bq = 0; bq < 2; ++bq) acc[a][bq] = zero8();
+  // Window of at most KW destination columns (an upsampling by ~2): the column weights are computed once, and every row of
+  // the window issues its KW loads TOGETHER and unconditionally (clamped column, weight 0 outside the hits) -- with the loads
+  // behind per-pixel hit tests the kernel was a chain of dependent load -> use round trips (2.4-2.9 TB/s of its traffic).
+  // (fmaf(0, g, acc) leaves acc unchanged for finite g: same sums, same order as resize_bwd_kernel.)
+  constexpr int KW = 8;
+  // tighten the loose window to the destination rows / columns whose y0 (x0) lies in [yi0 - 1, yi0 + 1] ([xi0 - 1, xi0 + 1]):
+  // y0 is monotone in j, so these are one run; a pixel outside it cannot touch the 2x2 block
+  {
+    int i0, i1;
+    float l0, l1;
+    while (ja < jb && (ac_src(sy, ja, h, i0, i1, l0, l1), i0 < yi0 - 1)) ++ja;
+    while (jb > ja && (ac_src(sy, jb, h, i0, i1, l0, l1), i0 > yi0 + 1)) --jb;
+    while (ka < kb && (ac_src(sx, ka, w, i0, i1, l0, l1), i0 < xi0 - 1)) ++ka;
+    while (kb > ka && (ac_src(sx, kb, w, i0, i1, l0, l1), i0 > xi0 + 1)) --kb;
+  }
+  if (kb - ka + 1 <= KW) {
+    float wxs[KW][2];
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      wxs[kk][0] = wxs[kk][1] = 0.f;
+      if (ka + kk <= kb) {
+        int x0, x1;
+        float lx0, lx1;
+        ac_src(sx, ka + kk, w, x0, x1, lx0, lx1);
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq) wxs[kk][bq] = (x0 == xi0 + bq ? lx0 : 0.f) + (x1 == xi0 + bq ? lx1 : 0.f);
+      }
+    }
+    for (int j = ja; j <= jb; j += 2) {                  // two rows per iteration: 2 * KW loads in flight
+      float wy[2][2];
+      const T* rowp[2];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int jj = min(j + rr, jb);
+        int y0, y1;
+        float ly0, ly1;
+        ac_src(sy, jj, h, y0, y1, ly0, ly1);
+        const bool live = j + rr <= jb;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) wy[rr][a] = live ? (y0 == yi0 + a ? ly0 : 0.f) + (y1 == yi0 + a ? ly1 : 0.f) : 0.f;
+        rowp[rr] = ddst + ((size_t)n * H + jj) * W * ldddst + choff + c;
+      }
+      F8 g[2][KW];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) g[rr][kk] = load8<T>(rowp[rr] + (size_t)min(ka + kk, W - 1) * ldddst);
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk)
+#pragma unroll
+          for (int bq = 0; bq < 2; ++bq)
+            if (wxs[kk][bq] != 0.f) {                      // a column reaches one or two of the block's columns, not all
+#pragma unroll
+              for (int a = 0; a < 2; ++a) {
+                const float wgt = wy[rr][a] * wxs[kk][bq];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[a][bq].v[q] = fmaf(wgt, g[rr][kk].v[q], acc[a][bq].v[q]);
+              }
+            }
+    }
+  } else
   for (int j = ja; j <= jb; ++j) {
     int y0, y1;
     float ly0, ly1;
