@@ -95,6 +95,20 @@ class VGGBlock(nn.Module):
         return self._half(x, None, self.conv2, self.bn2, None, pool, out_view)
 
 
+_SIDE_STREAMS = {}
+
+
+def _overlap_lstm(t: torch.Tensor, training: bool) -> bool:
+    """The TemporalEncoder's recurrence occupies one workgroup per sample (16-32 of the 256 CUs) for ~0.45 ms forward and
+    ~0.9 ms backward at the reference's 828 steps: in training it runs on a side stream, beside the first encoder blocks
+    (forward) and -- autograd replays a node on its forward stream -- beside the encoder's backward.  Not under a process
+    group (the gradient buckets of dist.GradSync are flushed from one stream) and not in eval (hipGraph sessions, latency)."""
+    if not (training and t.is_cuda) or os.environ.get("MAU_OVERLAP_LSTM", "1") == "0":
+        return False
+    dist = torch.distributed
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 class TemporalEncoder(nn.Module):
     """LSTM(1->hidden) last hidden state -> Linear, src/model.py:23-34."""
 
@@ -112,6 +126,25 @@ class TemporalEncoder(nn.Module):
             _, (h_n, _) = lstm(x.unsqueeze(-1))
             h = h_n[-1]
         return F_.Linear.apply(h, self.fc.weight, self.fc.bias)
+
+    def forward_async(self, x):
+        """forward() on the side stream of x's device; returns (embedding, join): call join() on the consuming stream
+        before the embedding's first use."""
+        dev = x.device
+        side = _SIDE_STREAMS.get(dev)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)                       # the series and the parameters (last optimizer step) are ready
+        with torch.cuda.stream(side):
+            out = self.forward(x)
+        x.record_stream(side)
+
+        def join():
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_stream(side)
+            out.record_stream(cur)
+        return out, join
 
 
 class MetadataEncoder(nn.Module):
@@ -251,13 +284,19 @@ class UrbanPredictor_unet(_NetBase):
         return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]))
 
     def forward(self, maps, temp_series, metadata):
-        temporal_emb = self.temporal_encoder(temp_series) if self.temporal_embeddings else None
+        join = None
+        if self.temporal_embeddings and _overlap_lstm(temp_series, self.training):
+            temporal_emb, join = self.temporal_encoder.forward_async(temp_series)
+        else:
+            temporal_emb = self.temporal_encoder(temp_series) if self.temporal_embeddings else None
         meta_emb = self.meta_encoder(metadata) if self.metadata_embeddings else None
         x = self._entry(maps)
         p, x0_0 = self._block_pool(self.conv0_0, x)
         p, x1_0 = self._block_pool(self.conv1_0, p)
         p, x2_0 = self._block_pool(self.conv2_0, p)
         x4_0, x3_0 = self._block_pool(self.conv3_0, p)
+        if join is not None:
+            join()
         x4_0 = self._fused_block(self.conv4_0, x4_0, [e for e in (temporal_emb, meta_emb) if e is not None])
         x3_1 = self._dec(self.conv3_1, x3_0, x4_0)
         x2_1 = self._dec(self.conv2_1, x2_0, x3_1)
@@ -356,9 +395,12 @@ class UrbanPredictor_unetpp(_NetBase):
         return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]), out_view=out_view)
 
     def forward(self, maps, temp_series, metadata):
-        temporal_emb = self.temporal_encoder(temp_series)
+        join = None
+        if _overlap_lstm(temp_series, self.training):
+            temporal_emb, join = self.temporal_encoder.forward_async(temp_series)
+        else:
+            temporal_emb = self.temporal_encoder(temp_series)
         meta_emb = self.meta_encoder(metadata)
-        emb = torch.cat([temporal_emb, meta_emb], dim=1).float()           # src/model.py:103
         x = self._entry(maps)
         # Row buffers: the nodes x^{i,0..} of one resolution are written side by side into one (N,H,W,slots*C) buffer, so
         # that "cat of the earlier nodes of the row" is a view.  Needs 64-channel-aligned blocks and a 16-bit dtype.
@@ -381,6 +423,9 @@ class UrbanPredictor_unetpp(_NetBase):
         r0, r1, r2 = row_hw(0, 4), row_hw(1, 3), row_hw(2, 2)
         p, x0_0 = self._block_pool(self.conv0_0, x, r0[0])         # (the skip feeds every node of the row)
         p, x1_0 = self._block_pool(self.conv1_0, p, r1[0])
+        if join is not None:
+            join()
+        emb = torch.cat([temporal_emb, meta_emb], dim=1).float()           # src/model.py:103
         x0_1 = self._node(self.conv0_1, [x0_0], x1_0, emb, r0[1])
         p, x2_0 = self._block_pool(self.conv2_0, p, r2[0])
         x1_1 = self._node(self.conv1_1, [x1_0], x2_0, emb, r1[1])

@@ -365,6 +365,37 @@ def test_training_step_is_bitwise_reproducible(mau, prec):
         assert torch.equal(res[0][3][k], res[1][3][k]), k
 
 
+@pytest.mark.parametrize("model_type", ["unet", "unet++"])
+def test_lstm_side_stream_overlap_is_bitwise_neutral(mau, model_type, monkeypatch):
+    """In training the TemporalEncoder runs on a side stream (forward beside the first encoder blocks, backward -- replayed by
+    autograd on its forward stream -- beside the encoder's backward): outputs, loss and EVERY gradient must equal the
+    single-stream run bit for bit, at the reference's sequence length, three steps in a row (stream joins, allocator reuse)."""
+    g = torch.Generator().manual_seed(51)
+    x, ts, md = torch.randn(3, 6, 64, 64, generator=g).cuda(), torch.randn(3, 828, generator=g).cuda(), torch.randn(3, 4, generator=g).cuda()
+    tgt = torch.randn(3, 2, 64, 64, generator=g).cuda()
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MAU_OVERLAP_LSTM", flag)
+        torch.manual_seed(50)
+        net = mau.UrbanPredictor(model_type, 6, 828, 16, 4, 16, 96, 2, base_filters=32, temporal_embeddings=True).cuda().set_precision("bf16").train()
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, fused=True)
+        steps = []
+        for _ in range(3):
+            out = net(x, ts, md)
+            out = out[-1] if isinstance(out, (list, tuple)) else out
+            loss = mau.compute_loss_mse(out, tgt)["total"]
+            loss.backward()
+            steps.append((out.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+            opt.step()
+            opt.zero_grad()
+        res.append(steps)
+    for (o0, l0, g0), (o1, l1, g1) in zip(*res):
+        assert torch.equal(o0, o1) and torch.equal(l0, l1)
+        assert g0.keys() == g1.keys() and any("temporal_encoder.lstm" in k for k in g0)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+
+
 @pytest.mark.parametrize("name", ["g5_unet_even.npz", "g5_unet_odd.npz", "g6_unetpp.npz"])
 def test_fp16_mode_full_model(mau, name):
     """fp16 mode (v_mfma_f32_32x32x16_f16, fp32 accumulation; BASELINE configs[4]): eval and train outputs against the
