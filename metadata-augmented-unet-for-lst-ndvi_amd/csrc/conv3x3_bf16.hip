@@ -1,27 +1,29 @@
-// conv3x3_bf16.hip -- the throughput kernel: bf16 3x3 convolution (forward and data gradient) as an
-// im2col-free implicit GEMM on v_mfma_f32_32x32x16_bf16, written for gfx950.
+// conv3x3_bf16.hip -- the throughput kernel: 16-bit (bf16 / fp16) 3x3 convolution, forward and data gradient, as an
+// im2col-free implicit GEMM on the gfx950 matrix cores.
 //
-//   workgroup : 16x16 output pixels x BN output channels (BN = 64: 4 waves, BN = 128: 8 waves)
-//   wave      : 64 pixels (4 tile rows) x 64 channels = 2x2 accumulator tiles of 32x32
-//               -> one ds_read_b128 per MFMA (LDS array half idle), 64 accumulator registers
-//   K loop    : stages of KC = 16 input channels; a stage = the 18x18-pixel halo tile (32 B per
-//               pixel) + the 9 x BN x 16 weight slab, i.e. 9 taps x one k16 MFMA step
-//   staging   : global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), two LDS stages: the loads of
-//               stage k+1 are in flight while stage k is multiplied; one barrier per stage.
-//               The LDS image is lane-linear (DMA rule) and XOR-swizzled THROUGH THE SOURCE ADDRESS:
-//               16-byte half `hf` of row r lives in slot hf ^ ((r >> 3) & 1), which makes the
-//               ds_read_b128 of 16 consecutive rows hit 16 distinct 16-byte bank slots.
-//   padding   : out-of-image halo pixels and channels beyond the tensor DMA from a 16-byte zero page
-//   broadcast : channels >= C0 DMA from the per-image embedding vector (fuse_embeddings, reference
-//               src/model.py:248-259) -- the tiled map never exists in HBM
-//   epilogue  : bias, BatchNorm partial statistics from the fp32 accumulators (wave shuffles + LDS),
-//               output tile staged through LDS and stored as whole 128-byte pixel rows
-//   grid      : 1-D persistent; every XCD owns a contiguous range of pixel tiles (image order) and runs the cout
-//               tiles of one pixel tile back to back: its L2 serves halo overlap and input re-reads; pure speed,
-//               no correctness dependence.
+//   workgroup : TH x 16 output pixels (TH = 16 | 32 | 64) x BN output channels (64 | 128), 4 or 8 waves (Geo<BN, MT, NW>);
+//               persistent, 1-D grid; every XCD owns a contiguous range of pixel tiles (image order) and runs the cout tiles of
+//               one pixel tile back to back: its L2 serves halo overlap and input re-reads (pure speed)
+//   wave      : MT x 32 pixels x 64 channels; 64 or 128 fp32 accumulator registers
+//   stage     : KC = 16 input channels: the (TH + 2) x 18 halo tile (32 B per pixel) + the 9 x BN x 16 weight slab, staged by
+//               LDS-DMA (no VGPR round trip) into two LDS buffers: stage k + 1 lands while stage k is multiplied
+//   loader    : FAST = buffer_load ... lds with (resource, scalar stage offset, per-lane item-constant offset): tensor x |
+//               tensor x1 (virtual concat) | per-image embedding vector (fuse_embeddings, reference src/model.py:248-259:
+//               the tiled map never exists in HBM); the hardware range check supplies the zero padding.  !FAST = 64-bit
+//               select-only addresses + a zero page (channel counts off the 16-channel grid)
+//   multiply  : M16 (big tiles, even stage count): v_mfma_f32_16x16x32, two taps per MFMA, stages walked in pairs (PairSched);
+//               otherwise v_mfma_f32_32x32x16, dx-major with shared halo-row fragments (StageSched).  Both: fragment reads
+//               (inline-asm ds_read_b128, counted lgkmcnt) and wave-DMAs sit BETWEEN the MFMAs, from constexpr schedules.
+//               The kernel is bound by the clock the chip grants under MFMA load, not by issue slots
+//   image     : lane-linear (DMA rule); 32x32x16 path: XOR-swizzled THROUGH THE SOURCE ADDRESS (16-byte half hf of row r in
+//               slot hf ^ ((r >> 3) & 1): 16 consecutive rows hit 16 distinct bank slots); 16x16x32 path: unswizzled (its
+//               lane groups are conflict-free as they are)
+//   epilogue  : bias, BatchNorm partial statistics from the fp32 accumulators, or the inference affine + ReLU; 16-bit
+//               conversion, output tile staged through LDS and stored as whole 128-byte pixel rows
+//   build     : 72 instantiations; one (epilogue, operand type) slice per translation unit -- see "translation units" below
 //
 // Replaces nn.Conv2d(.,.,3,padding=1) + the statistics half of nn.BatchNorm2d of VGGBlock
-// (reference src/model.py:12-15).
+// (reference src/model.py:12-15), torch.cat([skip, up]) (:279-282) and fuse_embeddings (:248-259).
 #include <stdlib.h>
 #include "igemm_bf16_util.h"
 
