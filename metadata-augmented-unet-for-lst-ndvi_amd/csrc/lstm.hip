@@ -4,21 +4,23 @@
 // The reference's sequence is 828 monthly temperatures (conf/config.yaml:20) and the hidden size 96: 828 DEPENDENT steps of
 // a 384x96 matrix-vector product per sample -- pure latency, 2.4 MFLOP per step.  A library LSTM launches kernels per
 // step (measured: 26-30 ms forward + backward at B=32, more than the whole U-Net step).  Here:
-//   forward  : one workgroup per sample, 4*HP threads; thread 4u + q owns gate row q*H + u of W_hh in registers for the
-//              whole sequence; h_t in LDS (broadcast reads, double buffered); the four gates of a unit sit in one lane
-//              quad and meet through DPP broadcasts: ONE barrier per step; gate order i, f, g, o (torch).
-//   backward : one workgroup per sample, thread 4k + q owns column k of gate q's block of W_hh; per step each lane turns
-//              the quad-redundant (dh, dc) into the pre-activation gradient of its gate (saved activations are read one
-//              step ahead), publishes it in LDS (double buffered: ONE barrier per step), multiplies its column, and
-//              the unit's four partial products are added inside the quad.  The pre-activation gradients are also
-//              stored: the weight gradient dW_hh = sum_t dpre_t (x) h_{t-1} is NOT part of the recurrence -- it is
-//              one [4H x B*T] x [B*T x H] product computed afterwards by a tiled kernel (h_{t-1} = o_{t-1} *
-//              tanh(c_{t-1}) recomputed from the saved gates, no h tensor).  All partial sums are added in a fixed
-//              order by a second stage: bitwise reproducible, no atomics.
-//   measured : B=32, T=828, H=96 (scripts/lstm_bench.py): see DESIGN.md; the step is a latency chain (LDS broadcast of
-//              h, 48 packed FMAs, exp + rcp, barrier), not a throughput problem -- two gate rows per thread (half the
-//              LDS reads, twice the FMAs per thread) measured 23 % SLOWER.
-// Arithmetic is fp32 throughout; dot products on packed fp32 FMAs, gate nonlinearities on the hardware exp / rcp.
+//   forward  : one workgroup per sample, 4*HP threads, lane quad = hidden unit u; lane q multiplies the q-th QUARTER of h
+//              with the matching quarter of all four gate rows of the unit (4 x HP/4 weights in registers for the whole
+//              sequence; HP/4 values of h read from LDS per step instead of HP), quad butterflies (DPP) add the partials,
+//              lane q applies gate q's nonlinearity, the activations are exchanged inside the quad: ONE barrier per step;
+//              gate order i, f, g, o (torch)
+//   backward : one workgroup per sample; the saved activations of 8 steps are staged into LDS a block ahead and the gradients
+//              leave from LDS in bulk (no global memory inside the step loop); everything of a step that does not depend on
+//              (dh, dc) is computed one step ahead; the W_hh^T product is laid out over 16-lane groups (4 units x 1/16 of the
+//              4H gate gradients: a quarter of the LDS reads of a column per thread); ONE barrier per step.  The weight
+//              gradient dW_hh = sum_t dpre_t (x) h_{t-1} is NOT part of the recurrence -- it is one [4H x B*T] x [B*T x H]
+//              product computed afterwards by a tiled kernel (h_{t-1} = o_{t-1} * tanh(c_{t-1}) recomputed from the saved
+//              gates, no h tensor).  All partial sums are added in a fixed order: bitwise reproducible, no atomics.
+//   measured : B=32, T=828, H=96 (scripts/lstm_bench.py): forward 0.44 ms (533 ns/step), backward 0.92 ms; the step is a
+//              dependency chain on ONE CU (LDS exchange, ~100 scalar FMAs per thread, exp + rcp, barrier: ~1250 cycles), not a
+//              throughput problem -- two gate rows per thread measured 23 % slower, packed FMAs (also hipcc's SLP-packed ones:
+//              built with -fno-slp-vectorize) slower than scalar.  In training the model runs it on a side stream.
+// Arithmetic is fp32 throughout; gate nonlinearities on the hardware exp / rcp.
 #include "mau_common.h"
 
 namespace mau {
