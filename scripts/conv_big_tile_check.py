@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Exact-integer check of the big-tile convolution variants (the shapes the unit tests are too small to select), through the
-C ABI: forward with BatchNorm partial sums, data gradient (no bias), inference epilogue; one and two tensor sources; ragged
+C ABI: forward with BatchNorm partial sums, data gradient (no bias), inference epilogue, weight gradient; one and two tensor sources; ragged
 image sizes.  MAU_CONV_M16=0 selects the 32x32x16 loop for the big tiles (default: 16x16x32 where the stage count is even)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -53,7 +53,21 @@ for code, dt in ((MAU_BF16, torch.bfloat16), (MAU_F16, torch.float16)):
              wf.data_ptr(), bias.data_ptr(), sc.data_ptr(), sh.data_ptr(), y2.data_ptr(), y2.shape[-1], Cout, None, code, N, H, W, st)
         torch.cuda.synchronize()
         ok_p = torch.equal(y2[..., :Cout].float(), torch.relu(ref * sc + sh).to(dt).float())
-        print(f"{str(dt)[6:]:9s} N={N:3d} {H}x{W} C0={C0} C1={C1} E={E} Cout={Cout}: fwd {ok_y} stats {ok_s} dgrad {ok_d} post {ok_p}", flush=True)
-        bad += not (ok_y and ok_s and ok_d and ok_p)
+        # weight gradient (split-K slabs + fixed-order sum): exact on integer data while the sums stay below 2^24
+        xs = torch.randint(-1, 2, (N, H, W, C0), device="cuda").float(); x1s = torch.randint(-1, 2, (N, H, W, max(C1, 8)), device="cuda").float()
+        dys = torch.randint(-1, 2, (N, H, W, Cout), device="cuda").float()
+        xins = torch.cat([xs, x1s[..., :C1]], -1) if C1 else xs
+        if E: xins = torch.cat([xins, emb.view(N, 1, 1, E).expand(N, H, W, E)], -1)
+        refw = torch.nn.grad.conv2d_weight(xins.permute(0, 3, 1, 2), (Cout, cin + E, 3, 3), dys.permute(0, 3, 1, 2), padding=1)
+        acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, cin + E), device="cuda")
+        dw = torch.empty(Cout, cin + E, 3, 3, device="cuda")
+        xsl, x1sl, dysl = xs.to(dt).contiguous(), x1s.to(dt).contiguous(), dys.to(dt).contiguous()
+        call("mau_conv3x3_wgrad2", xsl.data_ptr(), xsl.shape[-1], C0, x1sl.data_ptr() if C1 else None, x1sl.shape[-1] if C1 else 0, C1, *eargs,
+             dysl.data_ptr(), dysl.shape[-1], Cout, acc.data_ptr(), code, N, H, W, st)
+        call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, cin + E), dw.data_ptr(), Cout, cin + E, st)
+        torch.cuda.synchronize()
+        ok_w = torch.equal(dw, refw) if float(refw.abs().max()) < 2 ** 24 else torch.allclose(dw, refw, rtol=1e-6)
+        print(f"{str(dt)[6:]:9s} N={N:3d} {H}x{W} C0={C0} C1={C1} E={E} Cout={Cout}: fwd {ok_y} stats {ok_s} dgrad {ok_d} post {ok_p} wgrad {ok_w}", flush=True)
+        bad += not (ok_y and ok_s and ok_d and ok_p and ok_w)
 print("FAILED" if bad else "ALL OK")
 sys.exit(1 if bad else 0)
