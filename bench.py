@@ -5,6 +5,9 @@
 
 A "step" is the inner training step of the reference (src/train.py:243-256) on one batch of
 synthetic input already resident in HBM: forward, MSE criterion, backward, AdamW step, zero_grad.
+On one GPU the step is captured once into a hipGraph (mau_amd.GraphedTrainStep; --no-graph = launched
+kernel by kernel from Python) and the K timed steps are K replays; under torch.distributed.run (N > 1)
+the step is eager, with the RCCL collectives overlapped from Python hooks.
 Workload (BASELINE.json configs[1] / configs[3]): U-Net, base_filters 64, 6x256x256 tiles + 4-dim
 metadata, B = 32 per GPU, bf16 MFMA arithmetic with fp32 accumulation, fp32 master weights.
 Prints ONE JSON line on rank 0 (contract in the task description) carrying `roofline` (dominant
@@ -34,12 +37,13 @@ def conv_flops(N, H, W, Cin, Cout):
 
 class ConvTimer:
     """Brackets every launch of the dominant kernel (conv3x3 implicit GEMM: forward and data-gradient
-    launches of mau_conv3x3_fwd) with events recorded on the stream the kernel is launched on
-    (torch's current stream, which is what the C ABI receives)."""
+    launches of mau_conv3x3_fwd) -- and, separately, of the weight-gradient kernel -- with events recorded on
+    the stream the kernel is launched on (torch's current stream, which is what the C ABI receives)."""
 
     def __init__(self, F_):
         self.F_ = F_
         self.records = []
+        self.wrecords = []
         self.enabled = False
         self._orig = F_.call
 
@@ -60,17 +64,33 @@ class ConvTimer:
                 orig(name, *args)
                 e1.record()
                 self.records.append((e0, e1, conv_flops(N, H, W, C0 + E, Cout)))
+            elif self.enabled and name == "mau_conv3x3_wgrad2":
+                # args: x, ldx, C0, x1, ldx1, C1, emb, emb_ws, E, dy, lddy, Cout, acc, dtype, N, H, W, stream
+                Cin, Cout, N, H, W = args[2] + args[5] + args[8], args[11], args[14], args[15], args[16]
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig(name, *args)
+                e1.record()
+                self.wrecords.append((e0, e1, conv_flops(N, H, W, Cin, Cout)))
             else:
                 orig(name, *args)
 
         self.F_.call = call
 
-    def summary(self):
-        if not self.records:
+    @staticmethod
+    def _sum(recs):
+        if not recs:
             return None
-        ms = [a.elapsed_time(b) for a, b, _ in self.records]
-        fl = [f for _, _, f in self.records]
+        ms = [a.elapsed_time(b) for a, b, _ in recs]
+        fl = [f for _, _, f in recs]
         return dict(launches=len(ms), total_ms=sum(ms), total_flop=sum(fl))
+
+    def summary(self):
+        return self._sum(self.records)
+
+    def wgrad_summary(self):
+        return self._sum(self.wrecords)
 
 
 def cpu_baseline(iters=5, warmup=2):
@@ -147,6 +167,8 @@ def main():
     ap.add_argument("--model-type", default="unet", choices=["unet", "unet++"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the train step kernel by kernel from Python instead of replaying "
+                                                            "its hipGraph (always so for N > 1 and for --infer)")
     ap.add_argument("--infer", action="store_true", help="inference-only images/s (eval mode, no_grad): BASELINE configs[4]")
     ap.add_argument("--channels", type=int, default=6, help="input channels (6 = BASELINE configs, 23 = the app's real shape)")
     ap.add_argument("--meta", type=int, default=4)
@@ -196,9 +218,17 @@ def main():
         with torch.no_grad():
             net(x, ts, md)
 
+    graphed = None
+    if not args.infer and world == 1 and not args.no_graph:
+        criterion = lambda o, t: mau_amd.compute_loss_mse(o, t)          # noqa: E731  (src/train.py:218-219)
+        graphed = mau_amd.GraphedTrainStep(net, opt, criterion, warmup=min(3, max(1, args.warmup)), copy_inputs=False)
+
     def step(i):
         if args.infer:
             return infer_step(i)
+        if graphed is not None:                       # fwd + MSE + bwd + AdamW step: eager while warming up, then one graph replay
+            losses[i] = graphed(x, ts, md, tgt)
+            return
         out = net(x, ts, md)
         loss = mau_amd.compute_loss_mse(out, tgt)["total"]
         if sync is not None:
@@ -220,16 +250,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    try:
+        for i in range(args.warmup):
+            step(i)
+        if graphed is not None and graphed.graph is None:     # fewer warm-up steps than the capture needs: capture before the clock starts
+            for i in range(graphed.warmup + 1 - args.warmup):
+                step(0)
+    except RuntimeError as e:
+        if graphed is None or "capturing the train step failed" not in str(e):
+            raise
+        # A broken capture leaves this process's stream state untrustworthy: run the eager bench in a CHILD process (never an
+        # exec: this process has initialised the GPU), relay its line and exit with its code.
+        import subprocess
+        print(f"bench.py: {e}; re-running eagerly in a child process", file=sys.stderr)
+        proc = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--no-graph"], stdout=subprocess.PIPE, text=True)
+        sys.stdout.write(proc.stdout)
+        raise SystemExit(proc.returncode)
     barrier()
-    timer.enabled = True
+    timer.enabled = graphed is None
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    timing_pass = "HIP events on the launch stream around every launch, inside the timed region"
+    if graphed is not None:
+        # A captured graph cannot carry timing events: the same K steps are launched eagerly (kernel by kernel, same resident
+        # batch, same kernels) right after the timed region, with the event brackets, for the per-kernel durations.
+        opt.zero_grad(set_to_none=True)
+        timer.enabled = True
+        for i in range(args.steps):
+            out = net(x, ts, md)
+            loss = mau_amd.compute_loss_mse(out, tgt)["total"]
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        timing_pass = (f"HIP events on the launch stream around every launch over {args.steps} eager steps of the same workload run "
+                       "right after the timed region (the timed steps are hipGraph replays, which cannot carry timing events)")
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -256,18 +316,21 @@ def main():
         return
 
     conv = timer.summary()
-    # PMC counters cannot be read inside this process: HBM traffic and the MFMA-busy fraction of the dominant kernel come from the
-    # separate rocprofv3 --pmc passes of THIS workload committed under profiles/ (scripts/profile.sh + scripts/summarize_profile.py)
+    wg = timer.wgrad_summary()
+    # PMC counters cannot be read inside this process: HBM traffic, the MFMA-busy fraction and the clock of the dominant kernel come
+    # from the separate rocprofv3 --pmc passes of THIS workload committed under profiles/ (scripts/profile.sh + scripts/summarize_profile.py)
     wkey = workload_key(args)
-    traffic, traffic_src, mfma_busy = args.traffic_bytes, "--traffic-bytes", None
+    traffic, traffic_src, rec = args.traffic_bytes, "--traffic-bytes", {}
     if traffic is None:
-        try:
-            with open(os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")) as f:
-                rec = json.load(f)[wkey]
-            traffic, mfma_busy = rec["hbm_bytes_per_launch"], rec.get("mfma_busy")
-            traffic_src = f"profiles/r2/pmc_summary.json[{wkey}]: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"
-        except (OSError, KeyError, ValueError):
-            traffic = None
+        for rnd in ("r3", "r2"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
+                    rec = json.load(f)[wkey]
+                traffic = rec["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{rnd}/pmc_summary.json[{wkey}]: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"
+                break
+            except (OSError, KeyError, ValueError):
+                traffic, rec = None, {}
     peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same rate
     achieved = conv["total_flop"] / (conv["total_ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -275,9 +338,20 @@ def main():
                 "kernel": "conv3x3_bf16_kernel (forward + data-gradient launches)",
                 "launches": conv["launches"], "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
                 "flop_per_launch_avg": conv["total_flop"] / conv["launches"],
-                "share_of_step_time": round(conv["total_ms"] / (elapsed * 1e3), 4),
-                "mfma_busy": mfma_busy,
+                "share_of_step_time": round(conv["total_ms"] / args.steps / (elapsed / args.steps * 1e3), 4),
+                "timing": timing_pass,
+                # PMC figures of the >= 0.3 ms dispatches only (GRBM_GUI_ACTIVE reads high on shorter ones): frac ~ busy x clock / 2.4 GHz
+                "mfma_busy": rec.get("mfma_busy_long"), "clock_ghz": rec.get("clock_ghz_long"),
+                "frac_long_dispatches": rec.get("frac_long"),
                 "hbm_gbps": round(traffic / (conv["total_ms"] * 1e-3 / conv["launches"]) / 1e9, 1) if traffic else None}
+    if wg is not None:
+        wach = wg["total_flop"] / (wg["total_ms"] * 1e-3) / 1e12
+        wrec = rec.get("wgrad", {})
+        wflop = wg["total_flop"] / wg["launches"]
+        roofline["wgrad"] = {"kernel": "wgrad_bf16_kernel", "achieved": round(wach, 2), "frac": round(wach / peak, 4),
+                             "launches": wg["launches"], "avg_launch_ms": round(wg["total_ms"] / wg["launches"], 4),
+                             "traffic": wrec.get("hbm_bytes_per_launch_pmc"), "algorithmic_bytes": wrec.get("algorithmic_bytes_per_launch"),
+                             "traffic_ratio": wrec.get("traffic_ratio"), "flop_per_launch_avg": wflop}
     result = {
         "metric": ("inference images/sec" if args.infer else "train images/sec") + f" ({S}x{S}x{args.channels}->2 {'U-Net' if args.model_type == 'unet' else 'U-Net++'}, B={B}/GPU)",
         "value": round(B * world * args.steps / elapsed, 2),
@@ -295,7 +369,8 @@ def main():
                                 + (f"temperature series of {args.seq_len} months, " if (args.seq_len != 10 or args.temporal_embeddings) else "")
                                 + ("eval-mode forward only (inference)" if args.infer else "fwd+MSE+bwd+AdamW (src/train.py:243-256)")),
                    "global_batch": B * world, "parallelism": f"dp{world}",
-                   "sync_bn": bool(world > 1 and not args.no_sync_bn)},
+                   "sync_bn": bool(world > 1 and not args.no_sync_bn),
+                   "launch": "hipGraph replay of the captured step" if graphed is not None else "eager (kernel by kernel)"},
         "rccl_ranks": rccl_ranks,
         "fwd_ms_per_tile": round(fwd_ms_per_tile, 4),
         "final_loss": float(losses[-1]),

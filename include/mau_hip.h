@@ -45,6 +45,7 @@ extern "C" {
 typedef void* mau_stream_t;
 
 /* ---- library ---------------------------------------------------------- */
+#define MAU_ABI_VERSION 2  /* 2: single-launch reductions (tickets), multi-tensor weight pack, fused BatchNorm passes */
 int mau_abi_version(void);
 const char* mau_last_error(void);
 /* 0 when the current HIP device is a gfx950 (MI355X); MAU_ERR_DEVICE otherwise. */
@@ -80,6 +81,15 @@ size_t mau_conv3x3_packed_elems(int dtype, int nout, int nin);
  * inputs of mau_conv3x3_fwd for the same dtype (MAU_BF16 permutes the rows inside every 64-row block). */
 int mau_conv3x3_pack_weights(const float* w_oihw, void* wf, void* wd, int dtype, int Cout, int Cin,
                              mau_stream_t stream);
+/* Every convolution of a network in ONE launch (an optimizer step changes all of them: 18 launches -> 1 in the U-Net).
+ * The caller keeps a table of mau_conv3x3_pack_desc_bytes()-sized rows: it fills row `index` on the HOST with
+ * mau_conv3x3_pack_desc_fill (arguments as mau_conv3x3_pack_weights; tile0 = *next_tile_host of the previous row, 0 for
+ * row 0; device pointers are only recorded), copies the table to the device once, and calls
+ * mau_conv3x3_pack_weights_multi(device table, rows, total tiles = the last *next_tile_host, dtype, stream). */
+size_t mau_conv3x3_pack_desc_bytes(void);
+int mau_conv3x3_pack_desc_fill(void* descs_host, int index, const float* w_oihw, void* wf, void* wd, int dtype, int Cout,
+                               int Cin, int tile0, int* next_tile_host);
+int mau_conv3x3_pack_weights_multi(const void* descs, int n, int total_tiles, int dtype, mau_stream_t stream);
 /* Rows of the BatchNorm partial-statistics slab the forward launch writes for an N x H x W batch with Cout output
  * channels: one per 8x16-pixel tile for MAU_F32; one per (workgroup tile of 16x16 or 32x16 pixels, wave row) for
  * MAU_BF16 -- the tile height is chosen per layer from how well its work items fill the 256 CUs. */
@@ -109,8 +119,8 @@ int mau_conv3x3_fwd2(const void* x, int ldx, int C0, const void* x1, int ldx1, i
                      int E, const void* wpk, const float* bias, const float* post_scale, const float* post_shift,
                      void* y, int ldy, int Cout, float* slab, int dtype, int N, int H, int W, mau_stream_t stream);
 /* Weight gradient  dW = x (*) dy  reduced over all pixels, in two steps:
- *   mau_conv3x3_wgrad        -> acc: fp32 split-K partial slabs [nsplit][9][Cout64][Cin64]
- *                               (nsplit = mau_conv3x3_wgrad_splits(...); MAU_F32: one slab, zeroed by the call)
+ *   mau_conv3x3_wgrad        -> acc: fp32 split-K partial slabs [nsplit][9][Cout64][Cin64], plain stores, every dtype
+ *                               (nsplit = mau_conv3x3_wgrad_splits(...))
  *   mau_conv3x3_unpack_wgrad -> sums the splits in fixed order and writes OIHW fp32 (Cout,Cin,3,3).
  * x is the convolution's input (with the optional broadcast `emb` / `emb_ws` as in mau_conv3x3_fwd). */
 int mau_conv3x3_wgrad_splits(int dtype, int N, int H, int W, int Cout, int Cin);
@@ -126,17 +136,27 @@ int mau_conv3x3_unpack_wgrad(const float* acc, int nsplit, float* dw_oihw, int C
 
 /* ---- BatchNorm2d (+ReLU) (src/model.py:13,15,16) ------------------------ */
 /* slab [rows][M] fp32 -> sums[M] fp64: column sums in two deterministic levels; `ws` is an fp64
- * workspace of mau_reduce_rows_ws_elems(rows, M) elements (NULL = single level, slow for many rows). */
+ * workspace of mau_reduce_rows_ws_elems(rows, M) elements (NULL = single level, slow for many rows).
+ * `tickets`: NULL = the two levels are two launches; else a ZEROED uint32 buffer of mau_reduce_tickets_elems() entries
+ * (zero again when the call's work has finished; not to be shared by calls running concurrently on two streams): the two
+ * levels are ONE launch -- the workgroup that draws a column block's last ticket adds that block's partials, in the same
+ * fixed order as the two-launch form (bit-identical results). */
 size_t mau_reduce_rows_ws_elems(int rows, int M);
-int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, double* ws,
+int mau_reduce_tickets_elems(void);
+int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, double* ws, unsigned* tickets,
                         mau_stream_t stream);
 /* same, and additionally the sums rounded to fp32 in `sums32` (the BatchNorm weight/bias gradients that autograd
- * returns, next to the fp64 sums the backward formula uses). */
+ * returns, next to the fp64 sums the backward formula uses).  append > 0 (single-launch form only): sums[M] = append --
+ * the local pixel count that is all-reduced together with the sums under data parallelism. */
 int mau_reduce_rows_f64_f32(const float* slab, int rows, int M, int ldrow, double* sums, float* sums32,
-                            double* ws, mau_stream_t stream);
+                            double* ws, unsigned* tickets, double append, mau_stream_t stream);
 /* same, result rounded to fp32. */
-int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, double* ws,
+int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, double* ws, unsigned* tickets,
                         mau_stream_t stream);
+/* Data-parallel forward: the statistics slab of mau_conv3x3_fwd [rows][2*Cout64] -> sums = [sum(y) (C) | sum(y^2) (C)]
+ * (+ sums[2*C] = append when append > 0), one launch; ws: mau_reduce_rows_ws_elems(rows, 2*C) fp64 elements. */
+int mau_bn_stats_sums_f64(const float* slab, int rows, int C, double* sums, double* ws, unsigned* tickets, double append,
+                          mau_stream_t stream);
 /* Train mode: sums = [sum(y) | sum(y^2)] (2*C fp64, already all-reduced over ranks when data
  * parallel), count = number of pixels summed.  Writes scale = gamma*invstd, shift = beta - mean*scale,
  * mean, invstd and updates running_mean / running_var (unbiased) / num_batches_tracked exactly as
@@ -148,12 +168,13 @@ int mau_bn_finalize_train(const double* sums, double count, const float* gamma, 
                           float momentum, float eps, float* scale, float* shift, float* mean,
                           float* invstd, int C, mau_stream_t stream);
 /* Single-GPU training shortcut: conv slab [rows][2*Cout64] -> (fp64 partials in `ws`,
- * mau_bn_stats_ws_elems(rows, C) elements) -> the outputs of mau_bn_finalize_train, in two launches. */
+ * mau_bn_stats_ws_elems(rows, C) elements) -> the outputs of mau_bn_finalize_train; one launch with `tickets` (see
+ * mau_reduce_rows_f64), two launches with tickets == NULL. */
 size_t mau_bn_stats_ws_elems(int rows, int C);
 int mau_bn_stats_finalize_train(const float* slab, int rows, double count, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                 float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
-                                double* ws, int C, mau_stream_t stream);
+                                double* ws, unsigned* tickets, int C, mau_stream_t stream);
 /* Eval mode: scale/shift from the running statistics (mean/invstd outputs optional, may be NULL). */
 int mau_bn_coeffs_eval(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, float* mean,

@@ -9,9 +9,10 @@ from .model import (MetadataEncoder, TemporalEncoder, UrbanPredictor, UrbanPredi
 from .losses import (compute_loss_l1_grad_ssim, compute_loss_mse, compute_loss_mse_gradient,   # noqa: F401
                      gradient_loss)
 from .inference import GraphedInference  # noqa: F401
+from .train_graph import GraphedTrainStep  # noqa: F401
 from .functional import mark_params_updated  # noqa: F401
 from . import data                      # noqa: F401  (input pipeline: compact tiles, device-side one-hot + RandomFlip)
 
 __all__ = ["UrbanPredictor", "UrbanPredictor_unet", "UrbanPredictor_unetpp", "VGGBlock", "MetadataEncoder",
            "TemporalEncoder", "compute_loss_mse", "compute_loss_mse_gradient", "compute_loss_l1_grad_ssim", "gradient_loss",
-           "GraphedInference", "mark_params_updated"]
+           "GraphedInference", "GraphedTrainStep", "mark_params_updated"]

@@ -35,6 +35,9 @@ PROTOTYPES = {
     "mau_conv3x3_kc": (_i, [_i]),
     "mau_conv3x3_packed_elems": (_sz, [_i, _i, _i]),
     "mau_conv3x3_pack_weights": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "mau_conv3x3_pack_desc_bytes": (_sz, []),
+    "mau_conv3x3_pack_desc_fill": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mau_conv3x3_pack_weights_multi": (_i, [_p, _i, _i, _i, _p]),
     "mau_conv3x3_num_pixel_tiles": (_i, [_i, _i, _i, _i, _i]),
     "mau_conv3x3_fwd": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_fwd2": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
@@ -44,12 +47,14 @@ PROTOTYPES = {
     "mau_conv3x3_wgrad2": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_unpack_wgrad": (_i, [_p, _i, _p, _i, _i, _p]),
     "mau_reduce_rows_ws_elems": (_sz, [_i, _i]),
-    "mau_reduce_rows_f64": (_i, [_p, _i, _i, _i, _p, _p, _p]),
-    "mau_reduce_rows_f64_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
-    "mau_reduce_rows_f32": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "mau_reduce_tickets_elems": (_i, []),
+    "mau_reduce_rows_f64": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "mau_reduce_rows_f64_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _d, _p]),
+    "mau_reduce_rows_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "mau_bn_stats_sums_f64": (_i, [_p, _i, _i, _p, _p, _p, _d, _p]),
     "mau_bn_finalize_train": (_i, [_p, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
     "mau_bn_stats_ws_elems": (_sz, [_i, _i]),
-    "mau_bn_stats_finalize_train": (_i, [_p, _i, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i, _p]),
+    "mau_bn_stats_finalize_train": (_i, [_p, _i, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mau_bn_coeffs_eval": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p]),
     "mau_bn_relu_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _i64, _i, _p]),
     "mau_bn_relu_apply_pool": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),

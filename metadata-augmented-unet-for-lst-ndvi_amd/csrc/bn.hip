@@ -4,6 +4,10 @@
 //                       -> [RCCL all-reduce when data parallel] -> bn_finalize_train -> bn_relu_apply
 // Backward:             bn_relu_bwd_reduce (partials) -> reduce_rows -> [all-reduce] -> bn_relu_bwd_apply
 // All reductions are slab + fixed-order second stage: bitwise reproducible, no float atomics.
+// The two levels of a slab reduction are ONE launch when the caller passes a ticket buffer: every workgroup of a column
+// block publishes its fp64 partial and takes a ticket; the workgroup that draws the last ticket adds the partials in the
+// SAME fixed order as the two-launch form (bit-identical), finalizes, and resets the ticket (launch tail: 36 launches fewer
+// per train step of the U-Net).  Hand-off protocol: cdna_hip_programming.md Guideline 16 (agent-scope release / acquire).
 // All of these kernels are HBM-streaming: 16-byte (bf16) / 32-byte (f32) vectors per lane.
 #include <stdlib.h>
 #include "mau_common.h"
@@ -61,6 +65,88 @@ static int reduce_rows_launch(const float* slab, int rows, int M, int ldrow, Out
   return check_launch("reduce_rows_kernel");
 }
 
+// ---- "the last workgroup of a column block runs the second level" ----
+// Every thread of the block has issued its partial stores.  Returns true in exactly one block per ticket: the one that
+// arrives last; by then the partials of all n blocks are visible to it.  Producer side: each storing wave drains its
+// stores (vmcnt(0)), workgroup barrier, one lane releases at agent scope and takes the ticket.  Consumer side (the last
+// arriver): agent-scope acquire (invalidates this CU's L1: a line of the partial buffer may be resident from an earlier
+// launch), its completion waited for, barrier, then plain loads.  The ticket is reset for the next launch on the stream.
+__device__ __forceinline__ bool last_block_of(unsigned* ticket, unsigned n) {
+  __shared__ unsigned s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = t == n - 1 ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+// Single-launch form of reduce_rows_launch: grid (column blocks, chunks).  Output column j reads slab column
+// j (j < split) or j - split + gap (j >= split): the BatchNorm statistics slab keeps sum and sum of squares in two
+// 64-padded halves, the outputs are [C | C] dense.  Arithmetic and order are those of the two-launch form.
+template <typename OutT>
+__global__ __launch_bounds__(256) void reduce_rows_fused_kernel(const float* __restrict__ slab, int rows, int M, int ldrow, int split,
+                                                                int gap, double* __restrict__ part, unsigned* __restrict__ tickets,
+                                                                OutT* __restrict__ out, float* __restrict__ out32, double append) {
+  __shared__ double ps[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + cl;
+  const int col = j < split ? j : j - split + gap;
+  const int chunks = gridDim.y;
+  const int per = (rows + chunks - 1) / chunks;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s0 = 0.0, s1 = 0.0;
+  if (j < M) {
+    int r = r0 + rl;
+    for (; r + 4 < r1; r += 8) {
+      s0 += (double)slab[(size_t)r * ldrow + col];
+      s1 += (double)slab[(size_t)(r + 4) * ldrow + col];
+    }
+    if (r < r1) s0 += (double)slab[(size_t)r * ldrow + col];
+  }
+  ps[rl][cl] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && j < M) part[(size_t)blockIdx.y * M + j] = ps[0][cl] + ps[1][cl] + ps[2][cl] + ps[3][cl];
+  if (!last_block_of(tickets + blockIdx.x, (unsigned)chunks)) return;
+  // level 2: the chunks' partials in a fixed order (the order of reduce_rows_kernel<double, OutT> on one chunk)
+  s0 = s1 = 0.0;
+  if (j < M) {
+    int k = rl;
+    for (; k + 4 < chunks; k += 8) {
+      s0 += part[(size_t)k * M + j];
+      s1 += part[(size_t)(k + 4) * M + j];
+    }
+    if (k < chunks) s0 += part[(size_t)k * M + j];
+  }
+  ps[rl][cl] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && j < M) {
+    const double v = ps[0][cl] + ps[1][cl] + ps[2][cl] + ps[3][cl];
+    out[j] = (OutT)v;
+    if (out32 != nullptr) out32[j] = (float)v;
+  }
+  if (append > 0.0 && blockIdx.x == 0 && threadIdx.x == 0) out[M] = (OutT)append;    // the local pixel count travels with the sums
+}
+
+template <typename OutT>
+static int reduce_rows_fused_launch(const float* slab, int rows, int M, int ldrow, int split, int gap, OutT* out, double* ws,
+                                    unsigned* tickets, hipStream_t st, float* out32 = nullptr, double append = 0.0) {
+  const int chunks = reduce_chunks(rows);
+  MAU_LAUNCH((reduce_rows_fused_kernel<OutT>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, ldrow, split, gap, ws,
+             tickets, out, out32, append);
+  return check_launch("reduce_rows_fused_kernel");
+}
+
 __global__ void bn_finalize_train_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
                                          const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                          int64_t* nbt, float momentum, float eps, float* __restrict__ scale,
@@ -111,6 +197,81 @@ __global__ __launch_bounds__(256) void bn_finalize_from_partials_kernel(const do
     if (k < chunks) {
       s0 += part[(size_t)k * 2 * ldp + c];
       q0 += part[(size_t)k * 2 * ldp + ldp + c];
+    }
+  }
+  ps[kl][cl] = s0 + s1;
+  pq[kl][cl] = q0 + q1;
+  __syncthreads();
+  if (kl != 0 || c >= C) return;
+  const double s = (ps[0][cl] + ps[1][cl]) + (ps[2][cl] + ps[3][cl]);
+  const double q = (pq[0][cl] + pq[1][cl]) + (pq[2][cl] + pq[3][cl]);
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_o[c] = (float)mean;
+  invstd_o[c] = invstd;
+  if (rmean) {
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+  }
+}
+
+// Single-launch statistics reduce + finalize (single-GPU training): grid (cpad / 64, chunks); level 1 = the conv epilogue's
+// slab [rows][2 * cpad] -> fp64 partials [chunk][2 * cpad]; the last workgroup of a channel block adds the chunks in the
+// order of bn_finalize_from_partials_kernel and finalizes its 64 channels (bit-identical to the two-launch form).
+__global__ __launch_bounds__(256) void bn_stats_finalize_fused_kernel(const float* __restrict__ slab, int rows, int cpad,
+                                                                      double* __restrict__ part, unsigned* __restrict__ tickets,
+                                                                      double count, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta, float* __restrict__ rmean,
+                                                                      float* __restrict__ rvar, int64_t* nbt, float momentum,
+                                                                      float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                                                      float* __restrict__ mean_o, float* __restrict__ invstd_o, int C) {
+  __shared__ double ps[4][64], pq[4][64];
+  const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;                          // (c < cpad always: the slab's pad columns are zeros)
+  const int chunks = gridDim.y, ld = 2 * cpad;
+  const int per = (rows + chunks - 1) / chunks;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
+  {
+    int r = r0 + kl;
+    for (; r + 4 < r1; r += 8) {
+      s0 += (double)slab[(size_t)r * ld + c];
+      q0 += (double)slab[(size_t)r * ld + cpad + c];
+      s1 += (double)slab[(size_t)(r + 4) * ld + c];
+      q1 += (double)slab[(size_t)(r + 4) * ld + cpad + c];
+    }
+    if (r < r1) {
+      s0 += (double)slab[(size_t)r * ld + c];
+      q0 += (double)slab[(size_t)r * ld + cpad + c];
+    }
+  }
+  ps[kl][cl] = s0 + s1;
+  pq[kl][cl] = q0 + q1;
+  __syncthreads();
+  if (kl == 0) {
+    part[(size_t)blockIdx.y * ld + c] = ps[0][cl] + ps[1][cl] + ps[2][cl] + ps[3][cl];
+    part[(size_t)blockIdx.y * ld + cpad + c] = pq[0][cl] + pq[1][cl] + pq[2][cl] + pq[3][cl];
+  }
+  if (!last_block_of(tickets + blockIdx.x, (unsigned)chunks)) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  s0 = q0 = s1 = q1 = 0.0;
+  if (c < C) {
+    int k = kl;
+    for (; k + 4 < chunks; k += 8) {
+      s0 += part[(size_t)k * ld + c];
+      q0 += part[(size_t)k * ld + cpad + c];
+      s1 += part[(size_t)(k + 4) * ld + c];
+      q1 += part[(size_t)(k + 4) * ld + cpad + c];
+    }
+    if (k < chunks) {
+      s0 += part[(size_t)k * ld + c];
+      q0 += part[(size_t)k * ld + cpad + c];
     }
   }
   ps[kl][cl] = s0 + s1;
@@ -402,20 +563,44 @@ extern "C" {
 
 size_t mau_reduce_rows_ws_elems(int rows, int M) { return (size_t)reduce_chunks(rows) * M; }
 
-int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, double* ws, mau_stream_t stream) {
+int mau_reduce_tickets_elems(void) { return 64; }            // one ticket per 64-column block: M <= 4096 columns
+
+#define MAU_REQUIRE_TICKETS(M) MAU_REQUIRE(tickets == nullptr || ceil_div((M), 64) <= mau_reduce_tickets_elems(), "reduce_rows: more than 4096 columns")
+
+int mau_reduce_rows_f64(const float* slab, int rows, int M, int ldrow, double* sums, double* ws, unsigned* tickets,
+                        mau_stream_t stream) {
   MAU_REQUIRE(slab && sums && rows > 0 && M > 0 && ldrow >= M, "reduce_rows: bad arguments");
+  MAU_REQUIRE_TICKETS(M);
+  if (tickets && ws) return reduce_rows_fused_launch<double>(slab, rows, M, ldrow, M, 0, sums, ws, tickets, (hipStream_t)stream);
   return reduce_rows_launch<double>(slab, rows, M, ldrow, sums, ws, (hipStream_t)stream);
 }
 
 int mau_reduce_rows_f64_f32(const float* slab, int rows, int M, int ldrow, double* sums, float* sums32, double* ws,
-                            mau_stream_t stream) {
+                            unsigned* tickets, double append, mau_stream_t stream) {
   MAU_REQUIRE(slab && sums && sums32 && rows > 0 && M > 0 && ldrow >= M, "reduce_rows: bad arguments");
+  MAU_REQUIRE_TICKETS(M);
+  MAU_REQUIRE(append <= 0.0 || (tickets && ws), "reduce_rows: the appended count needs the single-launch form (ws and tickets)");
+  if (tickets && ws)
+    return reduce_rows_fused_launch<double>(slab, rows, M, ldrow, M, 0, sums, ws, tickets, (hipStream_t)stream, sums32, append);
   return reduce_rows_launch<double>(slab, rows, M, ldrow, sums, ws, (hipStream_t)stream, sums32);
 }
 
-int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, double* ws, mau_stream_t stream) {
+int mau_reduce_rows_f32(const float* slab, int rows, int M, int ldrow, float* out, double* ws, unsigned* tickets,
+                        mau_stream_t stream) {
   MAU_REQUIRE(slab && out && rows > 0 && M > 0 && ldrow >= M, "reduce_rows: bad arguments");
+  MAU_REQUIRE_TICKETS(M);
+  if (tickets && ws) return reduce_rows_fused_launch<float>(slab, rows, M, ldrow, M, 0, out, ws, tickets, (hipStream_t)stream);
   return reduce_rows_launch<float>(slab, rows, M, ldrow, out, ws, (hipStream_t)stream);
+}
+
+// [sum | sum of squares] of a conv-epilogue statistics slab [rows][2 * cpad] -> sums[0..C) | sums[C..2C), one launch
+// (the data-parallel forward: these sums are all-reduced before mau_bn_finalize_train)
+int mau_bn_stats_sums_f64(const float* slab, int rows, int C, double* sums, double* ws, unsigned* tickets, double append,
+                          mau_stream_t stream) {
+  MAU_REQUIRE(slab && sums && ws && tickets && rows > 0 && C > 0, "bn_stats_sums: bad arguments");
+  MAU_REQUIRE_TICKETS(2 * C);
+  const int cpad = round_up(C, 64);
+  return reduce_rows_fused_launch<double>(slab, rows, 2 * C, 2 * cpad, C, cpad, sums, ws, tickets, (hipStream_t)stream, nullptr, append);
 }
 
 int mau_bn_finalize_train(const double* sums, double count, const float* gamma, const float* beta,
@@ -432,11 +617,18 @@ size_t mau_bn_stats_ws_elems(int rows, int C) { return (size_t)reduce_chunks(row
 
 int mau_bn_stats_finalize_train(const float* slab, int rows, double count, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
-                                float* scale, float* shift, float* mean, float* invstd, double* ws, int C, mau_stream_t stream) {
+                                float* scale, float* shift, float* mean, float* invstd, double* ws, unsigned* tickets, int C,
+                                mau_stream_t stream) {
   MAU_REQUIRE(slab && ws && gamma && beta && scale && shift && mean && invstd && rows > 0 && C > 0 && count > 0, "bn_stats_finalize_train: bad arguments");
   MAU_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_finalize_train: running_mean/var must come together");
   hipStream_t st = (hipStream_t)stream;
   const int cpad = round_up(C, 64), M = 2 * cpad, chunks = reduce_chunks(rows);
+  MAU_REQUIRE_TICKETS(cpad);
+  if (tickets) {                                              // one launch: the last workgroup of a channel block finalizes
+    MAU_LAUNCH(bn_stats_finalize_fused_kernel, dim3(cpad / 64, chunks), dim3(256), 0, st, slab, rows, cpad, ws, tickets, count, gamma,
+               beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, invstd, C);
+    return check_launch("bn_stats_finalize_fused_kernel");
+  }
   // level 1: the conv epilogue's slab [rows][2*cpad] -> fp64 partials [chunks][2*cpad]
   MAU_LAUNCH((reduce_rows_kernel<float, double>), dim3(ceil_div(M, 64), chunks), dim3(256), 0, st, slab, rows, M, M, ws, M, (float*)nullptr);
   // level 2 + finalize

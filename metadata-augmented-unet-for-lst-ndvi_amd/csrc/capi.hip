@@ -27,7 +27,7 @@ int check_launch(const char* what) {
 
 extern "C" {
 
-int mau_abi_version(void) { return 1; }
+int mau_abi_version(void) { return MAU_ABI_VERSION; }
 
 const char* mau_last_error(void) { return mau::g_err; }
 

@@ -8,7 +8,10 @@
 //                              K = 9 taps x 16 input channels per chunk; the (8+2)x(16+2) halo tile is
 //                              staged ONCE per chunk in LDS and re-read for the 9 taps at shifted rows.
 //   weight-gradient         :  M = 64 output channels, N = 64 input channels (x 9 taps kept in
-//                              accumulators), K = pixels; fp32 atomics into one slab.
+//                              accumulators), K = pixels; every workgroup owns a strided set of pixel tiles
+//                              (split-K) and writes its partial with plain stores into its own slab
+//                              [split][9][Cout64][Cin64]; unpack_wgrad_kernel adds the splits in a fixed order
+//                              (bitwise reproducible, no float atomics -- as the 16-bit path).
 // The templates are written on the element type T but only instantiated for float.
 //
 // Replaces nn.Conv2d(cin, cout, 3, padding=1) of VGGBlock (reference src/model.py:12,14), the
@@ -312,14 +315,16 @@ __global__ __launch_bounds__(NT) void conv3x3_wgrad_kernel(WgradP p) {
     }
   }
 
+  // partial slab of this split: [tap][CoutPad][CinPad], 128 contiguous bytes per half-wave, plain stores
   const int h = lane >> 5;
+  float* out = p.acc + (size_t)blockIdx.x * 9 * p.CoutPad * p.CinPad;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wco * 32 + acc_row(r, h);
       const int ci = ci0 + wci * 32 + (lane & 31);
-      atomicAdd(p.acc + ((size_t)tap * p.CoutPad + co) * p.CinPad + ci, acc[tap][r]);
+      out[((size_t)tap * p.CoutPad + co) * p.CinPad + ci] = acc[tap][r];
     }
   }
 }
@@ -342,13 +347,12 @@ __device__ __forceinline__ int pack_row_channel(int q) {
 // 1024 threads per block: 9 loads per thread in flight at once (with 256 threads a block's 36 dependent load rounds
 // put an 8.5 us floor under every launch).
 template <typename T>
-__global__ __launch_bounds__(1024) void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
-                                                           int Cout, int Cin, int tilesF) {
+__device__ __forceinline__ void pack_tile(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin,
+                                          int tilesF, int tidx, float (*tile)[PackKC<T>::value * 9 + 1]) {
   constexpr int KC = PackKC<T>::value;                 // 16
-  __shared__ float tile[64][KC * 9 + 1];
   const int CoutPad = (Cout + 63) / 64 * 64, CinPad = (Cin + 63) / 64 * 64;
-  const bool fwd = (int)blockIdx.x < tilesF;
-  const int t = fwd ? blockIdx.x : blockIdx.x - tilesF;
+  const bool fwd = tidx < tilesF;
+  const int t = fwd ? tidx : tidx - tilesF;
   const int rowBlocks = (fwd ? CoutPad : CinPad) / 64;
   const int rb = t % rowBlocks, chunk = t / rowBlocks;
   const int nRow = fwd ? Cout : Cin, nK = fwd ? Cin : Cout;
@@ -380,6 +384,31 @@ __global__ __launch_bounds__(1024) void pack_weights_kernel(const float* __restr
     for (int j = 0; j < 8; ++j) v.v[j] = tile[r][(k8 * 8 + j) * 9 + tap];
     store8<T>(out + (((size_t)chunk * 9 + tapOut) * RowPad + rb * 64 + pos) * KC + k8 * 8, v);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
+                                                           int Cout, int Cin, int tilesF) {
+  __shared__ float tile[64][PackKC<T>::value * 9 + 1];
+  pack_tile<T>(w, wf, wd, Cout, Cin, tilesF, blockIdx.x, tile);
+}
+
+// Every conv layer of a network in ONE launch (the optimizer has just changed all of them): a device-resident table of
+// (weights, packs, shape, first tile) rows, sorted by first tile; a workgroup finds its layer by a scan of the table
+// (wave-uniform scalar loads; <= a few dozen rows) and packs one tile of it exactly as pack_weights_kernel does.
+struct PackDesc {
+  const float* w;
+  void* wf;
+  void* wd;
+  int Cout, Cin, tilesF, tile0;
+};
+template <typename T>
+__global__ __launch_bounds__(1024) void pack_weights_multi_kernel(const PackDesc* __restrict__ descs, int n) {
+  __shared__ float tile[64][PackKC<T>::value * 9 + 1];
+  int i = 0;
+  while (i + 1 < n && (int)blockIdx.x >= descs[i + 1].tile0) ++i;
+  const PackDesc d = descs[i];
+  pack_tile<T>(d.w, (T*)d.wf, (T*)d.wd, d.Cout, d.Cin, d.tilesF, (int)blockIdx.x - d.tile0, tile);
 }
 
 // sum of the split-K partial slabs [nsplit][9][CoutPad][CinPad] (fixed order) -> OIHW (Cout,Cin,3,3).
@@ -435,14 +464,23 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   return check_launch("conv3x3_igemm_kernel");
 }
 
+// split-K of the parity-mode weight gradient: ~4 workgroups per CU, at most one per pixel tile, slabs under 256 MiB
+static int wgrad_f32_splits(int N, int H, int W, int Cout, int Cin) {
+  const int CoutPad = round_up(Cout, 64), CinPad = round_up(Cin, 64);
+  const int tilesOut = (CoutPad / 64) * (CinPad / 64);
+  const int nTiles = N * ceil_div(H, TH) * ceil_div(W, TW);
+  int splits = (device_shape().cus * 4 + tilesOut - 1) / tilesOut;
+  const size_t cap = ((size_t)256 << 20) / ((size_t)9 * CoutPad * CinPad * sizeof(float));
+  if ((size_t)splits > cap) splits = (int)cap;
+  if (splits > nTiles) splits = nTiles;
+  return splits < 1 ? 1 : splits;
+}
+
 template <typename T>
 static int launch_wgrad(const WgradP& p, hipStream_t st) {
   const size_t lds = wgrad_lds_bytes<T>();
   MAU_LDS_ATTR(lds, &conv3x3_wgrad_kernel<T>);
-  const int tilesOut = (p.CoutPad / 64) * (p.CinPad / 64);
-  int splits = (device_shape().cus * 4 + tilesOut - 1) / tilesOut;     // aim at ~4 workgroups per CU
-  if (splits > p.nTiles) splits = p.nTiles;
-  if (splits < 1) splits = 1;
+  const int splits = wgrad_f32_splits(p.N, p.H, p.W, p.Cout, p.Cin);
   dim3 grid(splits, p.CoutPad / 64, p.CinPad / 64);
   MAU_LAUNCH(conv3x3_wgrad_kernel<T>, grid, dim3(NT), lds, st, p);
   return check_launch("conv3x3_wgrad_kernel");
@@ -480,6 +518,28 @@ int mau_conv3x3_pack_weights(const float* w, void* wf, void* wd, int dtype, int 
   const int tilesD = wd ? (round_up(Cin, 64) / 64) * ceil_div(Cout, kc) : 0;
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(pack_weights_kernel<T>, dim3(tilesF + tilesD), dim3(1024), 0, st, w, (T*)wf, (T*)wd, Cout, Cin, tilesF));
   return check_launch("pack_weights_kernel");
+}
+
+size_t mau_conv3x3_pack_desc_bytes(void) { return sizeof(PackDesc); }
+
+int mau_conv3x3_pack_desc_fill(void* descs_host, int index, const float* w, void* wf, void* wd, int dtype, int Cout, int Cin,
+                               int tile0, int* next_tile_host) {
+  MAU_REQUIRE(descs_host && next_tile_host && index >= 0 && w && (wf || wd) && Cout > 0 && Cin > 0 && tile0 >= 0, "pack_desc_fill: bad arguments");
+  MAU_REQUIRE(dtype == MAU_F32 || dtype == MAU_BF16 || dtype == MAU_F16, "bad dtype %d", dtype);
+  const int kc = mau_conv3x3_kc(dtype);
+  const int tilesF = wf ? (round_up(Cout, 64) / 64) * ceil_div(Cin, kc) : 0;
+  const int tilesD = wd ? (round_up(Cin, 64) / 64) * ceil_div(Cout, kc) : 0;
+  PackDesc* d = reinterpret_cast<PackDesc*>(descs_host) + index;
+  d->w = w; d->wf = wf; d->wd = wd; d->Cout = Cout; d->Cin = Cin; d->tilesF = tilesF; d->tile0 = tile0;
+  *next_tile_host = tile0 + tilesF + tilesD;
+  return MAU_OK;
+}
+
+int mau_conv3x3_pack_weights_multi(const void* descs, int n, int total_tiles, int dtype, mau_stream_t stream) {
+  MAU_REQUIRE(descs && n > 0 && total_tiles > 0, "pack_weights_multi: bad arguments");
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(pack_weights_multi_kernel<T>, dim3(total_tiles), dim3(1024), 0, (hipStream_t)stream,
+                                       (const PackDesc*)descs, n));
+  return check_launch("pack_weights_multi_kernel");
 }
 
 int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout) {
@@ -525,7 +585,7 @@ int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_
 }
 
 int mau_conv3x3_wgrad_splits(int dtype, int N, int H, int W, int Cout, int Cin) {
-  return dtype != MAU_F32 ? wgrad_bf16_v2_splits(N, H, W, Cout, Cin) : 1;
+  return dtype != MAU_F32 ? wgrad_bf16_v2_splits(N, H, W, Cout, Cin) : wgrad_f32_splits(N, H, W, Cout, Cin);
 }
 
 size_t mau_conv3x3_wgrad_acc_elems(int dtype, int N, int H, int W, int Cout, int Cin) {
@@ -556,11 +616,7 @@ int mau_conv3x3_wgrad2(const void* x, int ldx, int C0, const void* x1, int ldx1,
     return launch_wgrad_bf16_v2(p, dtype == MAU_F16, st);        // split-K partial slabs, plain stores (no memset needed)
   }
   MAU_REQUIRE(dtype == MAU_F32, "bad dtype %d", dtype);
-  if (hipMemsetAsync(acc, 0, mau_conv3x3_wgrad_acc_elems(dtype, N, H, W, Cout, C0 + E) * sizeof(float), st) != hipSuccess) {
-    set_error("conv3x3_wgrad: hipMemsetAsync failed");
-    return MAU_ERR_HIP;
-  }
-  return launch_wgrad<float>(p, st);
+  return launch_wgrad<float>(p, st);                               // split-K partial slabs, plain stores (no memset needed)
 }
 
 int mau_conv3x3_wgrad(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* dy, int lddy,

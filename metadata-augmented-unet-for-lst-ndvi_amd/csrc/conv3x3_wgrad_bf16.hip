@@ -31,6 +31,7 @@
 //
 // Replaces autograd's weight gradient of nn.Conv2d(.,.,3,padding=1) (reference src/model.py:12,14
 // under loss.backward(), src/train.py:252).
+#include <stdlib.h>
 #include "igemm_bf16_util.h"
 
 namespace mau {
@@ -105,7 +106,7 @@ struct Sched {
 // KG = number of wave groups that split the tile rows of every stage between them: KG = 2 gives the
 // 64-channel variant 8 waves (two per SIMD) instead of 4.
 template <int BCO, int KG, bool F16, int NS>
-__global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int nsplit) {
+__global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int nsplit, int xcd_shift) {
   constexpr int NW = BCO / 16 * KG;                  // waves: (BCO/32) x 2 x KG
   constexpr int WCO = BCO / 32;
   constexpr int DYROW = BCO * 2;                     // bytes per dY row
@@ -128,7 +129,26 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wco = wave % WCO, wci = (wave / WCO) & 1, kg = wave / (2 * WCO);
-  const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
+  // ---- work item: (pixel split, co tile, ci tile) from the 1-D workgroup id ----
+  // The workgroups of one split stream the SAME pixels (dY tile shared by the ci tiles, X halo shared by the co tiles).
+  // Hardware deals workgroup ids round-robin over the XCDs (id % 8; speed only): with xcd_shift > 0 (nsplit a multiple of the XCD
+  // count) XCD k owns the splits = k (mod 8) and walks their tiles in order, so all tiles of a split are resident on ONE
+  // XCD at about the same time and its L2 serves the re-reads.  With id = split + nsplit * tile (the other form), a split
+  // count like 85 or 21 scattered the tiles of a split over all XCDs: conv0_1.conv1 read its 268 MB dY three times.
+  int split, tile_id;
+  {
+    const int nCo = p.CoutPad / BCO, tilesOut = nCo * (p.CinPad / BCI);
+    const int id = blockIdx.x;
+    if (xcd_shift > 0) {
+      const int k = id & ((1 << xcd_shift) - 1), j = id >> xcd_shift;
+      tile_id = j % tilesOut;
+      split = ((j / tilesOut) << xcd_shift) + k;
+    } else {
+      split = id % nsplit;
+      tile_id = id / nsplit;
+    }
+  }
+  const int co0 = (tile_id % (p.CoutPad / BCO)) * BCO, ci0 = (tile_id / (p.CoutPad / BCO)) * BCI;
   const unsigned short* __restrict__ xg = reinterpret_cast<const unsigned short*>(p.x);
   const unsigned short* __restrict__ x1g = reinterpret_cast<const unsigned short*>(p.x1);
   const unsigned short* __restrict__ dyg = reinterpret_cast<const unsigned short*>(p.dy);
@@ -221,7 +241,6 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
   // ---- split-K: this workgroup's pixel tiles ----
-  const int split = blockIdx.x;
   const int per = (p.nTiles + nsplit - 1) / nsplit;
   const int t0 = split * per, t1 = min(p.nTiles, t0 + per);
   if (t0 < t1) {
@@ -291,8 +310,7 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
     wait_vmcnt<0>();                                   // the idle re-fetch must land before the LDS is reused / released
   }
 
-  const int slab = blockIdx.x;
-  float* out = p.acc + (size_t)slab * 9 * p.CoutPad * p.CinPad;
+  float* out = p.acc + (size_t)split * 9 * p.CoutPad * p.CinPad;
   if constexpr (KG == 2) {
     // ---- the two wave groups add their accumulators through LDS (fixed order: group 0 + group 1), 3 taps per round ----
     __builtin_amdgcn_s_barrier();
@@ -327,6 +345,12 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
     }
 }
 
+// MAU_WGRAD_XCD=0: the id = split + nsplit * tile order and unconstrained split counts (same-process A/B; read per call)
+static inline bool wgrad_xcd_order() {
+  const char* e = getenv("MAU_WGRAD_XCD");
+  return e == nullptr || atoi(e) != 0;
+}
+
 template <int BCO, int KG, bool F16, int NS>
 static int launch(const WgradP& p, int nsplit, hipStream_t st) {
   constexpr int NW = BCO / 16 * KG;
@@ -338,8 +362,10 @@ static int launch(const WgradP& p, int nsplit, hipStream_t st) {
   constexpr size_t lds = NS * stage > red ? NS * stage : red;
   static_assert(lds <= 160 * 1024, "LDS budget");
   MAU_LDS_ATTR(lds, &wgrad_bf16_kernel<BCO, KG, F16, NS>);
-  dim3 grid(nsplit, p.CoutPad / BCO, p.CinPad / BCI);
-  MAU_LAUNCH((wgrad_bf16_kernel<BCO, KG, F16, NS>), grid, dim3(BCO * 4 * KG), lds, st, p, nsplit);
+  const DeviceShape ds = device_shape();
+  const int xcd_shift = (wgrad_xcd_order() && ds.xcds > 1 && nsplit % ds.xcds == 0) ? ds.xcd_shift : 0;
+  dim3 grid(nsplit * (p.CoutPad / BCO) * (p.CinPad / BCI));
+  MAU_LAUNCH((wgrad_bf16_kernel<BCO, KG, F16, NS>), grid, dim3(BCO * 4 * KG), lds, st, p, nsplit, xcd_shift);
   return check_launch("wgrad_bf16_kernel");
 }
 }  // namespace wg2
@@ -362,7 +388,9 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   int best = 1;
   double best_score = -1.0;
   const long cus = device_shape().cus;
+  const int xcds = wg2::wgrad_xcd_order() ? device_shape().xcds : 1;
   for (int s = 1; s <= smax; ++s) {                // s = workgroups along the split axis = partial slabs
+    if (s >= xcds && s % xcds != 0) continue;      // whole splits per XCD (see the kernel's work-item order)
     const long blocks = (long)outTiles * s;
     const long rounds = (blocks + cus - 1) / cus;
     const double eff = (double)blocks / (double)(rounds * cus);

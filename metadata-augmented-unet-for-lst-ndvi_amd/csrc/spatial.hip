@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void resize_bwd2_kernel(const T* __restrict__ 
   // Window of at most KW destination columns (an upsampling by ~2): the column weights are computed once, and every row of
   // the window issues its KW loads TOGETHER and unconditionally (clamped column, weight 0 outside the hits) -- with the loads
   // behind per-pixel hit tests the kernel was a chain of dependent load -> use round trips (2.4-2.9 TB/s of its traffic).
-  // (fmaf(0, g, acc) leaves acc unchanged for finite g: same sums, same order as resize_bwd_kernel.)
+  // (Zero-weight columns and rows are skipped: same sums, same order as resize_bwd_kernel.)
   constexpr int KW = 8;
   // tighten the loose window to the destination rows / columns whose y0 (x0) lies in [yi0 - 1, yi0 + 1] ([xi0 - 1, xi0 + 1]):
   // y0 is monotone in j, so these are one run; a pixel outside it cannot touch the 2x2 block
@@ -375,20 +375,25 @@ __global__ __launch_bounds__(256) void resize_bwd2_kernel(const T* __restrict__ 
       for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
         for (int kk = 0; kk < KW; ++kk) g[rr][kk] = load8<T>(rowp[rr] + (size_t)min(ka + kk, W - 1) * ldddst);
+      // A destination row reaches one or two of the block's rows; its weight for the other is exactly 0, and 0 * Inf would put a
+      // NaN into a source pixel that never read that destination pixel (fp16 training without loss scaling can overflow a
+      // gradient; ATen's adjoint only propagates non-finite values to true contributors).  The row weights depend on
+      // (blockIdx.y, j) only -- wave-uniform -- so the test is a scalar branch (readfirstlane), not an exec mask.
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-        for (int kk = 0; kk < KW; ++kk)
+        for (int a = 0; a < 2; ++a) {
+          if (__builtin_amdgcn_readfirstlane(__float_as_int(wy[rr][a])) == 0) continue;
 #pragma unroll
-          for (int bq = 0; bq < 2; ++bq)
-            if (wxs[kk][bq] != 0.f) {                      // a column reaches one or two of the block's columns, not all
+          for (int kk = 0; kk < KW; ++kk)
 #pragma unroll
-              for (int a = 0; a < 2; ++a) {
+            for (int bq = 0; bq < 2; ++bq)
+              if (wxs[kk][bq] != 0.f) {                    // a column reaches one or two of the block's columns, not all
                 const float wgt = wy[rr][a] * wxs[kk][bq];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) acc[a][bq].v[q] = fmaf(wgt, g[rr][kk].v[q], acc[a][bq].v[q]);
               }
-            }
+        }
     }
   } else
   for (int j = ja; j <= jb; ++j) {

@@ -243,9 +243,22 @@ class DeviceLoader:
     def __init__(self, loader, device, dtype: torch.dtype = torch.bfloat16):
         self.loader, self.device, self.dtype = loader, torch.device(device), dtype
         self.stream = torch.cuda.Stream(device=self.device)
+        self._epoch = 0
 
     def __len__(self):
         return len(self.loader)
+
+    @property
+    def sampler(self):
+        return getattr(self.loader, "sampler", None)
+
+    def set_epoch(self, epoch: int):
+        """Data parallel: reseed the DistributedSampler's permutation (the reference's single-process DataLoader reshuffles
+        every epoch by itself).  ``__iter__`` advances the epoch on its own when this is never called."""
+        self._epoch = int(epoch)
+        s = self.sampler
+        if hasattr(s, "set_epoch"):
+            s.set_epoch(self._epoch)
 
     def _stage(self, host: CompactBatch):
         with torch.cuda.stream(self.stream):
@@ -254,6 +267,8 @@ class DeviceLoader:
         return out, host                                   # keep the pinned buffers alive until the copy is consumed
 
     def __iter__(self):
+        self.set_epoch(self._epoch)          # a new permutation per pass over the data (no-op without a distributed sampler)
+        self._epoch += 1
         it = iter(self.loader)
         nxt = None
         try:
@@ -284,12 +299,18 @@ def create_dataloader(split: str, batch_size: int, shuffle: bool, dataset_type: 
     sampler, drop_last = None, False
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        # data parallel: every rank must run the SAME number of steps (one BatchNorm / gradient collective per layer and
-        # step, a missing partner deadlocks) on equally sized local batches -> disjoint equal shards, ragged tail dropped
-        # (SyncBN itself tolerates unequal local batch sizes: the pixel count travels with the statistics)
-        from torch.utils.data.distributed import DistributedSampler
-        sampler = DistributedSampler(ds, shuffle=shuffle, drop_last=True)
-        shuffle, drop_last = False, True
+        if shuffle:
+            # TRAINING loader, data parallel: every rank must run the SAME number of steps (one BatchNorm / gradient collective
+            # per layer and step, a missing partner deadlocks) on equally sized local batches -> disjoint equal shards, ragged
+            # tail dropped (SyncBN itself tolerates unequal local batch sizes: the pixel count travels with the statistics);
+            # DeviceLoader.set_epoch / __iter__ reseed the permutation every epoch
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(ds, shuffle=True, drop_last=True)
+            shuffle, drop_last = False, True
+        else:
+            # EVALUATION loader: eval-mode forwards issue no collective, so ranks may run different numbers of steps -- every
+            # sample is visited exactly once (rank r takes samples r, r + world, ...; nothing dropped, nothing repeated)
+            sampler = list(range(dist.get_rank(), len(ds), dist.get_world_size()))
     dl = DataLoader(ds, batch_size=batch_size, shuffle=shuffle, sampler=sampler, drop_last=drop_last, num_workers=num_workers,
                     collate_fn=collate_fn)
     return DeviceLoader(dl, device, dtype) if device is not None else dl

@@ -10,8 +10,11 @@ Two collectives per step family:
     reverse registration order (= backward arrival order) and each bucket is all-reduced
     asynchronously as soon as its last gradient has arrived, overlapping the rest of backward.
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages (default 32 MiB) keep
-    every link busy; tiny per-tensor messages would be latency-bound.  A bucket's gradients enter the
-    arena through one multi-tensor copy and are averaged by the collective (ReduceOp.AVG on RCCL).
+    every link busy; tiny per-tensor messages would be latency-bound.  The convolution weight
+    gradients (99.9 % of the bytes) are WRITTEN INTO the arena by the kernel that produces them
+    (``functional.ConvBNReLU.backward`` unpacks the split-K sum straight into the parameter's arena slot and
+    autograd adopts that view as ``p.grad``: no copy); the few small tensors left enter through one
+    multi-tensor copy per bucket.  The collective averages (ReduceOp.AVG on RCCL).
   * BatchNorm: per layer one all-reduce of [sum | sum of squares] (2C fp64) in forward and one of
     [sum dz | sum dz*xhat] in backward -- see ``functional.ConvBNReLU``; enabled by
     ``model.set_sync_bn(group)``.
@@ -40,7 +43,7 @@ def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
 
 
 class _Bucket:
-    __slots__ = ("lo", "hi", "params", "pending", "handle", "launched")
+    __slots__ = ("lo", "hi", "params", "pending", "handle", "launched", "streams")
 
     def __init__(self):
         self.lo = self.hi = 0
@@ -48,6 +51,7 @@ class _Bucket:
         self.pending = 0
         self.handle = None
         self.launched = False
+        self.streams = []
 
 
 class GradSync:
@@ -83,6 +87,11 @@ class GradSync:
                 cur.hi = off
         if cur.params:
             self.buckets.append(cur)
+        # the arena slot of every parameter, as a tensor of the parameter's shape: a kernel that produces the gradient may write
+        # it there directly (functional.ConvBNReLU.backward does, for the convolution weights)
+        for p in self.params:
+            lo, hi, _ = self._slot[id(p)]
+            p._mau_grad_slot = self.flat[lo:hi].view_as(p)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._active = False
         self._avg = self.group is not None and dist.get_backend(self.group) == "nccl"
@@ -93,15 +102,23 @@ class GradSync:
             b.pending = len(b.params)
             b.handle = None
             b.launched = False
+            b.streams = []
         self._active = True
 
     def _launch(self, b: _Bucket):
         """All gradients of the bucket have arrived: move them into the arena with ONE multi-tensor copy (instead of a
         small kernel per parameter), re-point ``p.grad`` at the arena slots, start the bucket's all-reduce."""
         b.launched = True
-        have = [p for p in b.params if p.grad is not None]
+        if b.streams:
+            # gradients of this bucket were produced on other streams too (the TemporalEncoder's backward runs on its side
+            # stream): the launching stream waits for them before the copy / the collective read the arena
+            cur = torch.cuda.current_stream()
+            for s in b.streams:
+                if s != cur:
+                    cur.wait_stream(s)
+        have = [p for p in b.params if p.grad is not None and p.grad.data_ptr() != p._mau_grad_slot.data_ptr()]
         if have:
-            views = [self.flat[self._slot[id(p)][0]:self._slot[id(p)][1]].view_as(p) for p in have]
+            views = [p._mau_grad_slot for p in have]
             torch._foreach_copy_(views, [p.grad for p in have])
             for p, v in zip(have, views):
                 p.grad = v
@@ -117,6 +134,10 @@ class GradSync:
         if not self._active:
             return
         b = self._slot[id(p)][2]
+        if p.is_cuda:
+            s = torch.cuda.current_stream(p.device)
+            if s not in b.streams:
+                b.streams.append(s)
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
@@ -143,6 +164,9 @@ class GradSync:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            if hasattr(p, "_mau_grad_slot"):
+                del p._mau_grad_slot
 
 
 def init_process_group_from_env(backend: Optional[str] = None):

@@ -126,35 +126,116 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_step
 _reg_step_hook(mark_params_updated)
 
 
+_TICKETS = {}
+
+
+def _tickets(dev) -> torch.Tensor:
+    """Zeroed uint32 ticket buffer of the single-launch reductions (``mau_reduce_rows_*``, ``mau_bn_stats_finalize_train``),
+    one per (device, stream): a launch leaves it zeroed, launches on one stream are ordered, and launches that may run
+    concurrently on two streams never share one."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(lib.mau_reduce_tickets_elems(), dtype=torch.int32, device=dev)
+    return t
+
+
+class PackGroup:
+    """The 3x3 convolution weights of ONE network: an optimizer step changes all of them, so all forward and data-gradient
+    packs are rebuilt by ONE launch (``mau_conv3x3_pack_weights_multi``; 18 launches -> 1 per step in the U-Net) into
+    PERSISTENT buffers -- re-packed in place, so the addresses a captured hipGraph or a frozen inference session holds stay
+    valid and always see the current weights.  Keyed like the per-parameter cache: (optimizer-step generation, every
+    weight's ``_version``, every storage address, dtype)."""
+
+    def __init__(self):
+        self.params: List[torch.Tensor] = []
+        self._state = {}
+
+    def add(self, w: torch.Tensor):
+        if not any(w is q for q in self.params):
+            self.params.append(w)
+            self._state = {}
+        w._mau_group = self
+
+    def _build(self, code: int, ptrs):
+        import ctypes
+        dev = self.params[0].device
+        dt = _DT[code]
+        wf = [torch.empty(lib.mau_conv3x3_packed_elems(code, w.shape[0], w.shape[1]), dtype=dt, device=dev) for w in self.params]
+        wd = [torch.empty(lib.mau_conv3x3_packed_elems(code, w.shape[1], w.shape[0]), dtype=dt, device=dev) for w in self.params]
+        nbytes = lib.mau_conv3x3_pack_desc_bytes()
+        host = ctypes.create_string_buffer(nbytes * len(self.params))
+        nxt = ctypes.c_int(0)
+        for i, w in enumerate(self.params):
+            call("mau_conv3x3_pack_desc_fill", ctypes.addressof(host), i, w.data_ptr(), wf[i].data_ptr(), wd[i].data_ptr(), code,
+                 w.shape[0], w.shape[1], nxt.value, ctypes.addressof(nxt))
+        table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
+        return {"ptrs": ptrs, "wf": wf, "wd": wd, "table": table, "tiles": nxt.value, "key": None}
+
+    def ensure(self, code: int):
+        ptrs = tuple(w.data_ptr() for w in self.params)
+        st = self._state.get(code)
+        if st is None or st["ptrs"] != ptrs:                      # first use, or the module moved (.to(), .cuda())
+            st = self._state[code] = self._build(code, ptrs)
+        key = (_GENERATION[0], tuple(w._version for w in self.params))
+        if st["key"] != key:
+            call("mau_conv3x3_pack_weights_multi", st["table"].data_ptr(), len(self.params), st["tiles"], code, _stream())
+            st["key"] = key
+            for w, f, d in zip(self.params, st["wf"], st["wd"]):
+                w._mau_pack = [(key[0], w._version, w.data_ptr(), code), f, d]
+        return st
+
+
 def pack_conv_weights(w: torch.Tensor, code: int, forward: bool = True, dgrad: bool = False):
-    """OIHW fp32 master weights -> (forward pack, data-gradient pack) in the activation dtype, ONE launch.
+    """OIHW fp32 master weights -> (forward pack, data-gradient pack) in the activation dtype.
 
     The packs are cached on the parameter and keyed by (optimizer-step generation, ``w._version``, storage address,
     dtype): they are rebuilt once per optimizer step (``mark_params_updated``), not once per forward.  A version-only
     key served stale weights from step 2 on with fused AdamW (``tests/test_gpu_model.py::
     test_multi_step_training_tracks_oracle`` is the regression test); the generation counter closes that hole.
+    A weight that belongs to a network (``PackGroup``) is re-packed together with all the others in one launch; a
+    stand-alone weight by one launch of its own.  Either way the buffers are persistent and re-packed IN PLACE.
     """
     cout, cin = w.shape[0], w.shape[1]
     key = (_GENERATION[0], w._version, w.data_ptr(), code)
     cache = getattr(w, "_mau_pack", None)
-    if cache is None or cache[0] != key:
-        cache = [key, None, None]
+    if cache is not None and cache[0] == key and (cache[1] is not None or not forward) and (cache[2] is not None or not dgrad):
+        return (cache[1] if forward else None), (cache[2] if dgrad else None)
+    group = getattr(w, "_mau_group", None)
+    if group is not None and os.environ.get("MAU_PACK_MULTI", "1") != "0":
+        group.ensure(code)
+        cache = w._mau_pack
+        return (cache[1] if forward else None), (cache[2] if dgrad else None)
+    dt = _DT[code]
+    if cache is None:
+        cache = [None, None, None]
         try:
             w._mau_pack = cache
         except (AttributeError, RuntimeError):      # a tensor that refuses attributes: no caching
             pass
-    need_f, need_d = forward and cache[1] is None, dgrad and cache[2] is None
+
+    def buf(old, n):                                # persistent: same dtype / device / size -> re-packed in place
+        if old is not None and old.dtype == dt and old.device == w.device and old.numel() == n:
+            return old
+        return torch.empty(n, dtype=dt, device=w.device)
+
+    stale = cache[0] != key
+    need_f = forward and (stale or cache[1] is None or cache[1].dtype != dt)
+    need_d = dgrad and (stale or cache[2] is None or cache[2].dtype != dt)
+    wf = buf(cache[1], lib.mau_conv3x3_packed_elems(code, cout, cin)) if need_f else None
+    wd = buf(cache[2], lib.mau_conv3x3_packed_elems(code, cin, cout)) if need_d else None
     if need_f or need_d:
-        dt = _DT[code]
-        src = w.detach()
-        wf = torch.empty(lib.mau_conv3x3_packed_elems(code, cout, cin), dtype=dt, device=w.device) if need_f else None
-        wd = torch.empty(lib.mau_conv3x3_packed_elems(code, cin, cout), dtype=dt, device=w.device) if need_d else None
-        call("mau_conv3x3_pack_weights", src.data_ptr(), wf.data_ptr() if need_f else None, wd.data_ptr() if need_d else None,
+        call("mau_conv3x3_pack_weights", w.detach().data_ptr(), wf.data_ptr() if need_f else None, wd.data_ptr() if need_d else None,
              code, cout, cin, _stream())
+    if stale:                                       # what was not re-packed now is out of date
+        cache[1] = wf
+        cache[2] = wd
+    else:
         if need_f:
             cache[1] = wf
         if need_d:
             cache[2] = wd
+    cache[0] = key
     return (cache[1] if forward else None), (cache[2] if dgrad else None)
 
 
@@ -219,6 +300,7 @@ def _all_reduce_(t: torch.Tensor, st: BNState):
 
 
 _OVERLAP_WGRAD = os.environ.get("MAU_OVERLAP_WGRAD", "0") != "0"      # measured: ~1 % (profiles/r1), off by default
+_FUSED_REDUCE = os.environ.get("MAU_FUSED_REDUCE", "1") != "0"        # single-launch slab reductions (A/B switch; bit-identical)
 _SIDE_STREAMS = {}
 
 
@@ -282,9 +364,14 @@ class ConvBNReLU(torch.autograd.Function):
             fz = st.frozen if st.frozen is not None else {}
             fkey = (_GENERATION[0], weight._version, gamma._version, rmean._version, rvar._version)
             if "wf" not in fz or fz["wf"].dtype != x.dtype or fz.get("key") != fkey:
-                fz["key"] = fkey        # (an optimizer step, mark_params_updated() or any in-place write re-derives the copies)
+                # (an optimizer step -- of ANY model: the generation counter is global --, mark_params_updated() or an in-place
+                #  write re-derives the copies.)  Everything is refreshed IN PLACE: the packs are persistent buffers and
+                # scale / shift are allocated once per session, so a live GraphedInference graph, which holds these
+                # addresses, replays with the new values instead of reading freed memory.
+                fz["key"] = fkey
                 fz["wf"] = pack_conv_weights(weight, code, forward=True, dgrad=False)[0]
-                fz["scale"], fz["shift"] = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+                if "scale" not in fz or fz["scale"].device != dev or fz["scale"].numel() != Cout:
+                    fz["scale"], fz["shift"] = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
                 call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                      st.eps, fz["scale"].data_ptr(), fz["shift"].data_ptr(), None, None, Cout, stream)
             _conv_fwd(x, x1, st, emb, emb_ws, E, fz["wf"], bias, (fz["scale"], fz["shift"]), y, Cout, None, code, N, H, W, stream)
@@ -305,21 +392,20 @@ class ConvBNReLU(torch.autograd.Function):
             slab = torch.empty((tiles, 2 * cpad), **f32)
             _conv_fwd(x, x1, st, emb, emb_ws, E, wf, bias, None, y, Cout, slab, code, N, H, W, stream)
             nbt_ptr = nbt.data_ptr() if nbt is not None else None
+            tk = _tickets(dev).data_ptr() if _FUSED_REDUCE else None
             if st.group is None:
-                # single GPU: slab -> fp64 partials -> (second level + finalize) in two launches
+                # single GPU: slab -> fp64 partials -> second level + finalize by the last workgroup, ONE launch
                 ws = torch.empty(lib.mau_bn_stats_ws_elems(tiles, Cout), dtype=torch.float64, device=dev)
                 call("mau_bn_stats_finalize_train", slab.data_ptr(), tiles, float(npix), gamma.data_ptr(), beta.data_ptr(),
                      rmean.data_ptr(), rvar.data_ptr(), nbt_ptr, st.momentum, st.eps, scale.data_ptr(), shift.data_ptr(),
-                     mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), Cout, stream)
+                     mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), tk, Cout, stream)
             else:
                 # SyncBN: ONE collective per layer carries [sum(y) | sum(y^2) | local pixel count]; the count is summed
                 # with the statistics, so ranks with different local batch sizes still agree on the global moments
                 sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
-                ws = torch.empty(2 * lib.mau_reduce_rows_ws_elems(tiles, Cout), dtype=torch.float64, device=dev)
-                call("mau_reduce_rows_f64", slab.data_ptr(), tiles, Cout, 2 * cpad, sums.data_ptr(), ws.data_ptr(), stream)
-                call("mau_reduce_rows_f64", slab.data_ptr() + 4 * cpad, tiles, Cout, 2 * cpad, sums.data_ptr() + 8 * Cout,
-                     ws.data_ptr() + 4 * ws.numel(), stream)
-                sums[2 * Cout] = float(npix)
+                ws = torch.empty(lib.mau_reduce_rows_ws_elems(tiles, 2 * Cout), dtype=torch.float64, device=dev)
+                call("mau_bn_stats_sums_f64", slab.data_ptr(), tiles, Cout, sums.data_ptr(), ws.data_ptr(), _tickets(dev).data_ptr(),
+                     float(npix), stream)
                 _all_reduce_(sums, st)
                 call("mau_bn_finalize_train", sums.data_ptr(), 0.0, gamma.data_ptr(), beta.data_ptr(),
                      rmean.data_ptr(), rvar.data_ptr(), nbt_ptr, st.momentum, st.eps, scale.data_ptr(), shift.data_ptr(),
@@ -383,12 +469,13 @@ class ConvBNReLU(torch.autograd.Function):
         sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
         ws = torch.empty(lib.mau_reduce_rows_ws_elems(rows, 2 * Cout), dtype=torch.float64, device=dev)
         g32 = torch.empty(2 * Cout, **f32)                   # [dbeta | dgamma]: the LOCAL sums, rounded to fp32 by the reducer
-        call("mau_reduce_rows_f64_f32", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), g32.data_ptr(), ws.data_ptr(), stream)
+        sync = st.training and st.group is not None
+        call("mau_reduce_rows_f64_f32", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), g32.data_ptr(), ws.data_ptr(),
+             _tickets(dev).data_ptr() if (_FUSED_REDUCE or sync) else None, float(npix) if sync else 0.0, stream)
         dgamma = g32[Cout:]
         dbeta = g32[:Cout]
         if st.training:
-            if st.group is not None:
-                sums[2 * Cout] = float(npix)                 # the global count travels with the sums (see forward)
+            if st.group is not None:                         # the global count travels with the sums (see forward)
                 _all_reduce_(sums, st)
                 sums_apply, count = sums, 0.0
             else:
@@ -405,7 +492,11 @@ class ConvBNReLU(torch.autograd.Function):
         if needs[3]:
             acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), **f32)
             emb_ws = torch.empty((N, E), dtype=y.dtype, device=dev) if E else None
-            dw = torch.empty_like(weight)
+            # data parallel (dist.GradSync): the split-K sum is written straight into the parameter's slot of the gradient arena
+            # and autograd adopts the returned view as weight.grad -- no copy into the arena later.  Only for the FIRST
+            # gradient of a step: an accumulating backward (weight.grad already set) must not overwrite what it adds to.
+            slot = getattr(weight, "_mau_grad_slot", None)
+            dw = slot.view_as(weight) if (slot is not None and weight.grad is None and slot.device == dev) else torch.empty_like(weight)
             wstream = stream
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream())
@@ -726,13 +817,14 @@ class Head(torch.autograd.Function):
         dout = dout.contiguous().float()
         da = torch.empty((N, H, W, pad8(C)), dtype=a.dtype, device=a.device)
         rows, rowlen = lib.mau_head_bwd_rows(N, H * W), lib.mau_head_bwd_rowlen(C, Co)
-        slab = torch.zeros((rows, rowlen), dtype=torch.float32, device=a.device)
+        slab = torch.empty((rows, rowlen), dtype=torch.float32, device=a.device)   # (the 7 unwritten columns per output channel are never read back)
         stream = _stream()
         call("mau_head_bwd", a.data_ptr(), _ld(a), w2.data_ptr(), out.data_ptr(), dout.data_ptr(), da.data_ptr(), pad8(C),
              slab.data_ptr(), tanh0, dtype_code(a.dtype), N, H * W, C, Co, stream)
         red = torch.empty(rowlen, dtype=torch.float32, device=a.device)
         ws = torch.empty(lib.mau_reduce_rows_ws_elems(rows, rowlen), dtype=torch.float64, device=a.device)
-        call("mau_reduce_rows_f32", slab.data_ptr(), rows, rowlen, rowlen, red.data_ptr(), ws.data_ptr(), stream)
+        call("mau_reduce_rows_f32", slab.data_ptr(), rows, rowlen, rowlen, red.data_ptr(), ws.data_ptr(),
+             _tickets(a.device).data_ptr() if _FUSED_REDUCE else None, stream)
         red = red.view(Co, pad8(C) + 8)
         dw = red[:, :C].reshape(wshape).contiguous()
         db = red[:, pad8(C)].contiguous()

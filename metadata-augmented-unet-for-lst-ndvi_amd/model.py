@@ -66,6 +66,7 @@ class VGGBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(out_channels)
         self.relu = nn.ReLU(inplace=True)
         self._rt: Optional[_Runtime] = None
+        self._group = None                # functional.PackGroup of the network this block belongs to (all weights re-packed in one launch)
         self._frozen = None               # [dict, dict] while a frozen inference session is active
         # a state-dict load through ANY container (nn.Module recursion calls _load_from_state_dict, not load_state_dict)
         # drops the frozen copies: they would keep serving the old weights and BatchNorm coefficients
@@ -77,6 +78,8 @@ class VGGBlock(nn.Module):
 
     def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d, x1: Optional[Act] = None, pool: bool = False, out_view=None):
         rt = self._rt or _Runtime()
+        if self._group is not None and getattr(conv.weight, "_mau_group", None) is not self._group:
+            self._group.add(conv.weight)          # (a deep copy of the network carries new Parameter objects)
         st = BNState(training=self.training and bn.training, C0=x.C, momentum=bn.momentum, eps=bn.eps,
                      group=rt.group, world=rt.world, grad_enabled=torch.is_grad_enabled(),
                      frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1],
@@ -101,12 +104,12 @@ _SIDE_STREAMS = {}
 def _overlap_lstm(t: torch.Tensor, training: bool) -> bool:
     """The TemporalEncoder's recurrence occupies one workgroup per sample (16-32 of the 256 CUs) for ~0.45 ms forward and
     ~0.9 ms backward at the reference's 828 steps: in training it runs on a side stream, beside the first encoder blocks
-    (forward) and -- autograd replays a node on its forward stream -- beside the encoder's backward.  Not under a process
-    group (the gradient buckets of dist.GradSync are flushed from one stream) and not in eval (hipGraph sessions, latency)."""
+    (forward) and -- autograd replays a node on its forward stream -- beside the encoder's backward (also under a process
+    group: dist.GradSync makes a bucket's launching stream wait for every stream that produced one of its gradients).
+    Not in eval (hipGraph sessions, latency) and not inside a captured train step (train_graph.GraphedTrainStep)."""
     if not (training and t.is_cuda) or os.environ.get("MAU_OVERLAP_LSTM", "1") == "0":
         return False
-    dist = torch.distributed
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    return not torch.cuda.is_current_stream_capturing()
 
 
 class TemporalEncoder(nn.Module):
@@ -119,12 +122,13 @@ class TemporalEncoder(nn.Module):
 
     def forward(self, x):
         lstm = self.lstm
-        if lstm.hidden_size <= F_.lib.mau_lstm_max_hidden():
-            # the whole (up to 828-step, conf/config.yaml:20) recurrence in one persistent HIP launch per direction
-            h = F_.LSTMLast.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
-        else:   # hidden sizes beyond one gate row per thread: the library LSTM (SURVEY 8a row a19 allows it)
-            _, (h_n, _) = lstm(x.unsqueeze(-1))
-            h = h_n[-1]
+        if lstm.hidden_size > F_.lib.mau_lstm_max_hidden():
+            # (the reference's configurations use 96 and 32, conf/config.yaml / test/evaluate.py:152-160; there is no second
+            #  backend behind this path: no nn.LSTM / MIOpen fallback)
+            raise NotImplementedError(f"TemporalEncoder: lstm hidden size {lstm.hidden_size} exceeds the persistent HIP kernel's "
+                                      f"limit of {F_.lib.mau_lstm_max_hidden()} (one gate row per thread)")
+        # the whole (up to 828-step, conf/config.yaml:20) recurrence in one persistent HIP launch per direction
+        h = F_.LSTMLast.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
         return F_.Linear.apply(h, self.fc.weight, self.fc.bias)
 
     def forward_async(self, x):
@@ -164,9 +168,13 @@ class _NetBase(nn.Module):
         self._rt = _Runtime()
 
     def _bind_runtime(self):
+        self._pack_group = F_.PackGroup()
         for m in self.modules():
             if isinstance(m, VGGBlock):
                 m._rt = self._rt
+                m._group = self._pack_group
+                self._pack_group.add(m.conv1.weight)
+                self._pack_group.add(m.conv2.weight)
 
     # -- extras -------------------------------------------------------------
     def set_precision(self, precision: str):
@@ -378,10 +386,11 @@ class UrbanPredictor_unetpp(_NetBase):
             self.final = nn.Conv2d(nb[0], out_channels, kernel_size=1)
         self._bind_runtime()
 
-    def _node(self, block: VGGBlock, skips: List[Act], below: Act, emb: torch.Tensor, out_view=None) -> Act:
+    def _node(self, block: VGGBlock, skips: List[Act], below: Act, emb: torch.Tensor, out_view=None, rows: bool = False) -> Act:
         # cat([skips..., _upsample_match(below, (H, W)), emb_map], 1), src/model.py:111-121,136-177
+        # rows: the skips sit side by side in one row buffer (an argument, not module state: forward stays re-entrant)
         fused_emb = (sum(s.C for s in skips) + below.C) % 8 == 0 and emb.shape[1] % 8 == 0
-        rows = out_view is not None or getattr(self, "_rows_active", False)
+        rows = rows or out_view is not None
         if fused_emb and self._fusable(skips[0]) and (len(skips) == 1 or rows):
             # [skips | up | broadcast(emb)] are three sources of the conv loader; with row buffers the skips of a row
             # already sit side by side (RowPrefix: a view, no copy)
@@ -405,8 +414,9 @@ class UrbanPredictor_unetpp(_NetBase):
         # Row buffers: the nodes x^{i,0..} of one resolution are written side by side into one (N,H,W,slots*C) buffer, so
         # that "cat of the earlier nodes of the row" is a view.  Needs 64-channel-aligned blocks and a 16-bit dtype.
         nb0 = self.conv0_0.conv2.out_channels
+        # The buffers are written by raw kernels through ``BNState.out_view`` and read through views: no torch in-place op may
+        # ever touch them (it would bump the version counter autograd checks for the saved slots).
         use_rows = self._rt.dtype != torch.float32 and nb0 % 64 == 0 and os.environ.get("MAU_VIRTUAL_CONCAT", "1") != "0"
-        self._rows_active = use_rows
         N, H, W = x.t.shape[0], x.t.shape[1], x.t.shape[2]
         hs, ws = [H], [W]
         for _ in range(3):
@@ -435,11 +445,10 @@ class UrbanPredictor_unetpp(_NetBase):
         x1_2 = self._node(self.conv1_2, [x1_0, x1_1], x2_1, emb, r1[2])
         x0_3 = self._node(self.conv0_3, [x0_0, x0_1, x0_2], x1_2, emb, r0[3])
         x4_0 = self.conv4_0(p)
-        x3_1 = self._node(self.conv3_1, [x3_0], x4_0, emb)
-        x2_2 = self._node(self.conv2_2, [x2_0, x2_1], x3_1, emb)
-        x1_3 = self._node(self.conv1_3, [x1_0, x1_1, x1_2], x2_2, emb)
-        x0_4 = self._node(self.conv0_4, [x0_0, x0_1, x0_2, x0_3], x1_3, emb)
-        self._rows_active = False
+        x3_1 = self._node(self.conv3_1, [x3_0], x4_0, emb, rows=use_rows)
+        x2_2 = self._node(self.conv2_2, [x2_0, x2_1], x3_1, emb, rows=use_rows)
+        x1_3 = self._node(self.conv1_3, [x1_0, x1_1, x1_2], x2_2, emb, rows=use_rows)
+        x0_4 = self._node(self.conv0_4, [x0_0, x0_1, x0_2, x0_3], x1_3, emb, rows=use_rows)
         if self.deep_supervision:
             return [F_.Head.apply(a.t, a.C, f.weight, f.bias, False)          # bare 1x1 convs, no tanh (src/model.py:180-185)
                     for a, f in ((x0_1, self.final1), (x0_2, self.final2), (x0_3, self.final3), (x0_4, self.final4))]

@@ -5,9 +5,11 @@
 The reference wraps the step in Optuna trials, wandb logging and a dataset that is not shipped
 (SURVEY D9); none of that is on the hot path.  This driver keeps: the flags, the study-name suffix
 rule (:79-87), seeding (:104), model construction (:194-207), optimizer / loss selection
-(:209-225), the inner step (:243-256), best-loss checkpointing in the exact ``.pth`` layout
-(:303-319) -- on synthetic batches with the loader's tuple layout (src/dataset.py:87-108).
-Single process, or data parallel under ``torch.distributed.run`` (RCCL).
+(:209-225), the inner step (:243-256), ``validate()`` (:20-60: eval-mode pass over a held-out split,
+sample-weighted mean of the criterion's total), best-VALIDATION checkpointing in the exact ``.pth``
+layout (:303-319) -- on synthetic batches with the loader's tuple layout (src/dataset.py:87-108).
+Single process (the train step is one hipGraph replay, ``train_graph.GraphedTrainStep``), or data
+parallel under ``torch.distributed.run`` (RCCL; eager step with overlapped collectives).
 """
 from __future__ import annotations
 
@@ -22,6 +24,7 @@ from .checkpoint import build_hyperparameters, save_checkpoint
 from .config import CONFIG
 from .dist import GradSync, init_process_group_from_env
 from .model import UrbanPredictor
+from .train_graph import GraphedTrainStep
 
 app = typer.Typer(add_completion=False)
 
@@ -37,21 +40,47 @@ def synthetic_batch(batch_size: int, device, gen: torch.Generator):
             mk(batch_size, len(ds.target_channels), e, e))
 
 
+def validate(model: torch.nn.Module, loader, criterion):
+    """Loss on the validation set (src/train.py:20-60): eval mode, no_grad, every batch's ``total`` weighted by its sample
+    count; a batch whose criterion raises ValueError is skipped; the model is put back into training mode.
+    Returns (mean loss, {}) -- ``float('inf')`` when no batch counted.  (The reference additionally averages
+    ``compute_all_loss``'s terms for wandb; logging is outside the hot path.)"""
+    n_meta = CONFIG.dataset.nb_metadata_features
+    model.eval()
+    total, num = 0.0, 0
+    with torch.no_grad():
+        for inputs, metadata, temp_series, _lengths, t1, t2, targets in loader:
+            metadata_full = torch.cat([metadata, t1, t2], dim=1) if n_meta >= 8 else metadata
+            outputs = model(inputs, temp_series, metadata_full)
+            try:
+                batch_loss = criterion(outputs, targets)["total"]
+                if batch_loss is not None:
+                    total += batch_loss.item() * len(inputs)
+                    num += len(inputs)
+            except ValueError as e:
+                typer.echo(f"Skipping batch in validation due to error: {e}")
+                continue
+    model.train()
+    if num == 0:
+        return float("inf"), {}
+    return total / num, {}
+
+
 @app.command()
 def main(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study_name: bool = False,
          temporal_embeddings: bool = True, metadata_embeddings: bool = True, study_name: str = "urban-predictor",
          model_type: str = "unet++", jobid: str = "", epochs: Optional[int] = None, steps_per_epoch: int = 20,
-         precision: str = "bf16"):
-    """The reference's CLI (src/train.py:62-73) + --epochs / --steps-per-epoch / --precision."""
+         precision: str = "bf16", val_batches: int = 2, graph: bool = True):
+    """The reference's CLI (src/train.py:62-73) + --epochs / --steps-per-epoch / --precision / --val-batches / --no-graph."""
     return run(device, wandblog, n_trials, force_study_name, temporal_embeddings, metadata_embeddings, study_name, model_type,
-               jobid, epochs, steps_per_epoch, precision)["best"]
+               jobid, epochs, steps_per_epoch, precision, val_batches, graph)["best"]
 
 
 def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study_name: bool = False,
         temporal_embeddings: bool = True, metadata_embeddings: bool = True, study_name: str = "urban-predictor",
         model_type: str = "unet++", jobid: str = "", epochs: Optional[int] = None, steps_per_epoch: int = 20,
-        precision: str = "bf16"):
-    """Body of the CLI as a function; returns {'best', 'model', 'optimizer', 'checkpoint_path'}."""
+        precision: str = "bf16", val_batches: int = 2, graph: bool = True):
+    """Body of the CLI as a function; returns {'best' (validation loss), 'model', 'optimizer', 'checkpoint_path', 'history'}."""
     assert model_type in ["unet", "unet++"], "model_type must be 'unet' or 'unet++'"          # src/train.py:78
     if not force_study_name:                                                                  # src/train.py:79-87
         study_name += "-emb" if temporal_embeddings and metadata_embeddings else "-tempemb" if temporal_embeddings \
@@ -74,8 +103,8 @@ def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study
         optimizer = torch.optim.SGD(model.parameters(), lr=cfg.learning_rate, momentum=cfg.momentum)
     elif cfg.optimizer == "Adam":
         optimizer = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
-    elif cfg.optimizer == "AdamW":
-        optimizer = torch.optim.AdamW(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
+    elif cfg.optimizer == "AdamW":      # one fused multi-tensor launch per step (the kernel bench.py times)
+        optimizer = torch.optim.AdamW(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay, fused=True)
     else:
         raise NotImplementedError(f"Optimizer {cfg.optimizer} not implemented.")
     if cfg.loss == "mse":                                                                     # src/train.py:218-225
@@ -94,37 +123,50 @@ def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study
     hyper = build_hyperparameters(cfg, model_type, temporal_embeddings, metadata_embeddings,
                                   CONFIG.dataset.input_channels, CONFIG.dataset.target_channels)
     gen = torch.Generator().manual_seed(CONFIG.seed + rank)
-    best, step, ckpt_path = float("inf"), 0, None
+    # held-out synthetic validation split (the reference's val_loader, src/train.py:183-192): drawn once, from its own generator
+    vgen = torch.Generator().manual_seed(CONFIG.seed + 7919 + rank)
+    val_loader = [synthetic_batch(cfg.batch_size, CONFIG.device, vgen) for _ in range(max(0, val_batches))]
+    clip = 5.0 if cfg.gradient_clipping > 0 else 0.0                                            # src/train.py:253-254
+    # one GPU: the step (forward, criterion, backward, clip, optimizer) is captured once and replayed (static shapes);
+    # data parallel: eager, the RCCL collectives are launched from autograd hooks while backward still runs
+    gstep = GraphedTrainStep(model, optimizer, criterion, clip_grad_norm=clip) if (graph and sync is None) else None
+    best, step, ckpt_path, history = float("inf"), 0, None, []
     for epoch in range(epochs if epochs is not None else cfg.epochs):
         model.train()
-        total = 0.0
+        total, num = 0.0, 0
         for _ in range(steps_per_epoch):
             inputs, metadata, temp_series, _lengths, t1, t2, targets = synthetic_batch(cfg.batch_size, CONFIG.device, gen)
             metadata_full = torch.cat([metadata, t1, t2], dim=1) if n_meta >= 8 else metadata  # src/train.py:244
-            outputs = model(inputs, temp_series, metadata_full)                             # src/train.py:245
-            batch_loss = criterion(outputs, targets).get("total", None)                     # src/train.py:247-249
-            if sync is not None:
-                sync.begin()
-            batch_loss.backward()
-            if sync is not None:
-                sync.finish()
-            if cfg.gradient_clipping > 0:
-                torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)                     # src/train.py:253-254
-            optimizer.step()
-            optimizer.zero_grad()
-            total += batch_loss.detach().cpu().item()                                       # src/train.py:258
+            if gstep is not None:
+                batch_loss = gstep(inputs, temp_series, metadata_full, targets)             # src/train.py:245-256 in one replay
+            else:
+                outputs = model(inputs, temp_series, metadata_full)                         # src/train.py:245
+                batch_loss = criterion(outputs, targets).get("total", None)                 # src/train.py:247-249
+                if sync is not None:
+                    sync.begin()
+                batch_loss.backward()
+                if sync is not None:
+                    sync.finish()
+                if clip > 0:
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), clip)                # src/train.py:253-254
+                optimizer.step()
+                optimizer.zero_grad()
+            total += batch_loss.detach().cpu().item() * len(inputs)                         # src/train.py:258-260
+            num += len(inputs)
             step += 1
-        epoch_loss = total / steps_per_epoch
+        epoch_loss = total / max(num, 1)
+        val_loss, _ = validate(model, val_loader, criterion)                                # src/train.py:286
+        history.append((epoch_loss, val_loss))
         if rank == 0:
-            typer.echo(f"epoch {epoch} step {step} train loss {epoch_loss:.6f}")
-            if epoch_loss < best:                                                           # src/train.py:303-319
-                best = epoch_loss
+            typer.echo(f"Epoch {epoch + 1} | step {step} | Train Loss: {epoch_loss:.6f} | Val Loss: {val_loss:.6f}")
+            if val_loss < best:                                                             # src/train.py:303-319
+                best = val_loss
                 name = f"{study_name}_trial_0_best_job{jobid}.pth"
                 ckpt_path = os.path.join(CONFIG.MODELS_DIR, name)
                 save_checkpoint(ckpt_path, model, optimizer, epoch=epoch, step=step, loss=best,
                                 hyperparameters=hyper, model_type=model_type, study_name=study_name, trial_id=0,
                                 metadata_input_length=n_meta)
-    return {"best": best, "model": model, "optimizer": optimizer, "checkpoint_path": ckpt_path}
+    return {"best": best, "model": model, "optimizer": optimizer, "checkpoint_path": ckpt_path, "history": history}
 
 
 if __name__ == "__main__":

@@ -1,0 +1,118 @@
+"""The inner training step of the reference (src/train.py:243-256) as ONE hipGraph.
+
+    step = GraphedTrainStep(model, optimizer, criterion)
+    for batch in loader:
+        loss = step(maps, temp_series, metadata, targets)        # forward + criterion + backward + optimizer.step
+
+A train step of the U-Net is ~190 kernel launches of 2 us .. 400 us; launched one by one from Python the
+short ones (weight packs, slab reductions, BatchNorm finalizes, split-K sums) leave the GPU waiting for
+the host.  The C ABI allocates nothing and never synchronises, the optimizer is torch's capturable fused
+AdamW, and every reduction keeps its workspace in torch's caching allocator -- so the whole step is
+capturable: the first ``warmup`` calls run eagerly (they are ordinary training steps on the batches they
+are given; they also warm the allocator and set the kernels' LDS attributes), the next call captures
+forward, criterion, backward and the optimizer step into a graph and replays it, every later call only
+refreshes the static input buffers and replays.  Results are bit-identical to the eager step
+(``tests/test_gpu_model.py::test_graphed_train_step_matches_eager``).
+
+Not captured (eager instead): data-parallel runs (``dist.GradSync`` overlaps RCCL collectives with
+backward from Python hooks), gradient clipping by norm under a process group, anything whose shapes
+change between calls.  A failed capture raises -- it is never retried or silently replaced.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from . import functional as F_
+
+
+def _make_capturable(optimizer: torch.optim.Optimizer):
+    """Adam-family optimizers keep their step count on the host unless ``capturable``: switch the flag and move counts
+    that already exist (a resumed optimizer) to the parameters' device.  Optimizers without the flag (SGD) need nothing."""
+    for group in optimizer.param_groups:
+        if "capturable" in group and not group["capturable"]:
+            group["capturable"] = True
+            for p in group["params"]:
+                st = optimizer.state.get(p)
+                if st and torch.is_tensor(st.get("step")) and not st["step"].is_cuda:
+                    st["step"] = st["step"].to(p.device, dtype=torch.float32)
+
+
+class GraphedTrainStep:
+    """``criterion(outputs, targets)`` returns the reference's loss dict (``{'total': ...}``, src/utils/losses.py) or a
+    scalar tensor.  ``clip_grad_norm``: max norm of ``torch.nn.utils.clip_grad_norm_`` (src/train.py:253-254), 0 = off.
+    ``copy_inputs=False``: the tensors of the capturing call ARE the static buffers -- later calls must pass the same
+    tensors (a resident synthetic batch, or buffers the loader fills in place); the default copies every batch in."""
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, criterion: Callable, warmup: int = 3,
+                 clip_grad_norm: float = 0.0, copy_inputs: bool = True):
+        self.model, self.optimizer, self.criterion = model, optimizer, criterion
+        self.warmup = max(1, int(warmup))
+        self.clip = float(clip_grad_norm)
+        self.copy_inputs = copy_inputs
+        self.calls = 0
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._in: Optional[Sequence[torch.Tensor]] = None
+        self.loss: Optional[torch.Tensor] = None
+        self.outputs: Optional[torch.Tensor] = None
+        _make_capturable(optimizer)
+
+    # ------------------------------------------------------------------ #
+    def _loss_of(self, outputs, targets):
+        losses = self.criterion(outputs, targets)
+        return losses.get("total") if isinstance(losses, dict) else losses
+
+    def _eager(self, maps, temp_series, metadata, targets):
+        outputs = self.model(maps, temp_series, metadata)                      # src/train.py:245
+        loss = self._loss_of(outputs, targets)                                 # :247-249
+        loss.backward()                                                        # :252
+        if self.clip > 0:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)  # :253-254
+        self.optimizer.step()                                                  # :255
+        self.optimizer.zero_grad(set_to_none=True)                             # :256
+        return loss.detach(), outputs.detach()
+
+    def _capture(self, batch):
+        if self.copy_inputs:
+            self._in = [t.detach().clone() for t in batch]
+        else:
+            self._in = list(batch)
+        self.optimizer.zero_grad(set_to_none=True)        # the captured backward ASSIGNS the gradients (static buffers of the graph)
+        F_.mark_params_updated()                          # the captured forward starts with the (captured) weight re-pack
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                outputs = self.model(self._in[0], self._in[1], self._in[2])
+                loss = self._loss_of(outputs, self._in[3])
+                loss.backward()
+                if self.clip > 0:
+                    torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+                self.optimizer.step()
+        except Exception as e:      # the stream / allocator state after a broken capture is not trustworthy: no silent fallback
+            raise RuntimeError(f"GraphedTrainStep: capturing the train step failed ({type(e).__name__}: {e}); "
+                               "run the step eagerly in a fresh process") from e
+        self.graph, self.loss, self.outputs = graph, loss.detach(), outputs.detach()
+
+    # ------------------------------------------------------------------ #
+    def __call__(self, maps, temp_series, metadata, targets):
+        """One training step on the batch; returns the loss (0-dim device tensor, overwritten by the next call)."""
+        self.calls += 1
+        if self.graph is None and self.calls <= self.warmup:
+            loss, self.outputs = self._eager(maps, temp_series, metadata, targets)
+            return loss
+        batch = (maps, temp_series, metadata, targets)
+        if self.graph is None:
+            self._capture(batch)
+        elif self.copy_inputs:
+            for dst, src in zip(self._in, batch):
+                if dst.shape != src.shape:
+                    raise ValueError(f"GraphedTrainStep was captured for shape {tuple(dst.shape)}, got {tuple(src.shape)}")
+                dst.copy_(src, non_blocking=True)
+        elif any(a.data_ptr() != b.data_ptr() or a.shape != b.shape for a, b in zip(self._in, batch)):
+            raise ValueError("GraphedTrainStep(copy_inputs=False): pass the tensors of the captured call (fill them in place)")
+        self.graph.replay()
+        # the replay changed every parameter behind Python's back: eager forwards that follow (validation) must re-pack
+        F_.mark_params_updated()
+        return self.loss

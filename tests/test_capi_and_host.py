@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libmau_hip.so does not export {s}"
     assert sorted(_lib.PROTOTYPES) == syms, (set(_lib.PROTOTYPES) ^ set(syms))
-    assert _lib.lib.mau_abi_version() == 1
+    assert _lib.lib.mau_abi_version() == 2
     # pure host-side helpers of the ABI are callable without a GPU
     assert _lib.lib.mau_conv3x3_kc(_lib.MAU_BF16) == 16 and _lib.lib.mau_conv3x3_kc(_lib.MAU_F32) == 16
     assert _lib.lib.mau_conv3x3_packed_elems(_lib.MAU_BF16, 64, 6) == 1 * 9 * 64 * 16
@@ -44,7 +44,11 @@ def test_library_exports_every_header_symbol():
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_F32, 2, 250, 250, 64) == 2 * 32 * 16
     s = _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 32, 32, 512, 1536)
     assert s >= 1 and (4 * 24 * s) % 256 == 0          # whole rounds of 256 CUs
-    assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_F32, 32, 32, 32, 512, 1536) == 1
+    # the fp32 parity mode also writes split-K partial slabs (plain stores + fixed-order sum: no float atomics anywhere)
+    s32 = _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_F32, 32, 32, 32, 512, 1536)
+    assert 1 <= s32 <= 32 * 4 * 2 and s32 * 9 * 512 * 1536 * 4 <= 256 << 20
+    assert _lib.lib.mau_conv3x3_wgrad_acc_elems(_lib.MAU_F32, 32, 32, 32, 512, 1536) == s32 * 9 * 512 * 1536
+    assert _lib.lib.mau_reduce_tickets_elems() >= 2 * 1024 // 64
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

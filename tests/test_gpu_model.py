@@ -133,15 +133,38 @@ def test_full_size_known_answer_fp32(mau):
     params = dict(net.named_parameters())
     gn = sum(float((p.grad.double() ** 2).sum()) for p in params.values() if p.grad is not None) ** 0.5
     assert abs(gn - s["grad_norm"]) < 1e-3 * s["grad_norm"]
+    # Per-parameter gradient norms against the committed known answers, bounded by a yardstick MEASURED HERE (as
+    # test_production_shape_fp32_vs_oracle does): the oracle's own fp32 gradients against an fp64 evaluation of the same graph
+    # on the same inputs.  |norm(a) - norm(b)| <= norm(a - b), so a parameter's norm may differ from the reference's by the
+    # length of the reference's own rounding-error vector -- times 2: the HIP path must be as close to the reference as the
+    # reference is to exact arithmetic (and never needs more than 1e-3 of the norm itself when that is larger).
+    torch.manual_seed(0)
+    flags = dict(temporal_embeddings=False, metadata_embeddings=True)
+    sd0 = R.init_state("unet", 6, 10, 64, 4, 64, 96, 2, **flags)
+    xc, tsc, mdc, tgtc = R.synthetic_batch(2)
+    sd32 = R.clone_state(sd0, requires_grad=True)
+    R.loss_mse(R.forward("unet", sd32, xc, tsc, mdc, True, **flags), tgtc)["total"].backward()
+    sd64 = {k: (v.detach().double().requires_grad_(True) if R.is_param(k) else v.detach().clone().double() if v.is_floating_point() else v.clone())
+            for k, v in sd0.items()}
+    R.loss_mse(R.forward("unet", sd64, xc.double(), tsc.double(), mdc.double(), True, **flags), tgtc.double())["total"].backward()
+    worst = (0.0, "", 0.0, 0.0)
     for k, ref_norm in s["per_param_grad_norm"].items():
         if k.endswith(".conv1.bias") or k.endswith(".conv2.bias"):
             continue
         got = float(params[k].grad.double().norm())
-        # 2e-3 of the parameter's own norm, plus 1e-6 of the WHOLE gradient's length: a parameter whose gradient is 2e-4 of the
-        # total (the metadata MLP's first layer: 4.7e-4 of 2.4) is a cancellation-heavy sum over 131k bottleneck pixels, and its
-        # norm moves by 3e-3 of itself (5e-7 of the total) with the rounding of the upsample's source coordinate alone --
-        # measured when ac_src stopped being FMA-contracted (csrc/spatial.hip), i.e. became ATen's arithmetic.
-        assert abs(got - ref_norm) <= 2e-3 * ref_norm + 1e-6 * s["grad_norm"], (k, got, ref_norm)
+        yard = float((sd32[k].grad.double() - sd64[k].grad).norm())                                  # reference fp32 vs fp64, this parameter
+        # (the oracle run on THIS host against the committed answer of the reference on another: the same bound applies)
+        assert abs(float(sd32[k].grad.double().norm()) - ref_norm) <= max(1e-3 * ref_norm, 2.0 * yard), k
+        dev = abs(got - ref_norm)
+        if dev / max(ref_norm, 1e-30) > worst[0]:
+            worst = (dev / max(ref_norm, 1e-30), k, dev, yard)
+        assert dev <= max(1e-3 * ref_norm, 2.0 * yard), (k, got, ref_norm, yard)
+        # and element-wise: relative L2 against the oracle's gradient within 2x the oracle's own fp32-vs-fp64 relative L2 (+1e-3)
+        e2 = rel_l2(params[k].grad.cpu(), sd32[k].grad)
+        y2 = rel_l2(sd32[k].grad, sd64[k].grad.float())
+        assert e2 <= 2.0 * y2 + 1e-3, (k, e2, y2)
+    print(f"known answer: worst per-parameter norm deviation {worst[0]:.2e} of the norm on {worst[1]} (|dev| {worst[2]:.3e}, reference "
+          f"fp32-vs-fp64 error vector there {worst[3]:.3e})")
 
 
 @pytest.mark.parametrize("model_type,B", [("unet", 2), ("unet++", 1)])
@@ -342,10 +365,11 @@ def test_virtual_concat_and_fused_pool_are_bitwise_equal_to_materialised(mau, mo
         assert torch.equal(res[0][2][k], res[1][2][k]), k
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
 def test_training_step_is_bitwise_reproducible(mau, prec):
     """Two identical steps from identical state give bit-identical outputs, loss, gradients and BatchNorm buffers: every
-    reduction of the path (BatchNorm statistics, split-K weight gradient, loss, head) is slab + fixed-order, no atomics."""
+    reduction of the path (BatchNorm statistics, split-K weight gradient, loss, head) is slab + fixed-order, no atomics --
+    in the fp32 parity mode too (its weight gradient wrote with float atomics until round 3)."""
     g = torch.Generator().manual_seed(41)
     x, ts, md = torch.randn(4, 6, 64, 64, generator=g).cuda(), torch.randn(4, 10, generator=g).cuda(), torch.randn(4, 4, generator=g).cuda()
     tgt = torch.randn(4, 2, 64, 64, generator=g).cuda()
@@ -667,3 +691,149 @@ def test_train_cli_writes_reference_checkpoint_and_reloads(mau, tmp_path):
     with torch.no_grad():
         assert torch.equal(loaded(x, ts, md), ref)
     assert checkpoint.run_inference(loaded, x.cpu(), md.cpu(), ts.cpu()).shape == (1, 2, 250, 250)
+
+
+def _train_n_steps(mau, model_type, prec, steps, graphed, seed=60, T=24):
+    """``steps`` training steps on a sequence of different batches; returns (losses, parameters, BN buffers)."""
+    flags = {} if model_type == "unet++" else dict(temporal_embeddings=True, metadata_embeddings=True)
+    torch.manual_seed(seed)
+    net = mau.UrbanPredictor(model_type, 6, T, 16, 4, 16, 24, 2, base_filters=16, **flags).cuda().set_precision(prec).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-3, fused=True, capturable=True)
+    crit = mau.compute_loss_mse_gradient
+    g = torch.Generator().manual_seed(seed + 1)
+    step = mau.GraphedTrainStep(net, opt, crit, warmup=2) if graphed else None
+    losses = []
+    for _ in range(steps):
+        x, ts, md = torch.randn(3, 6, 64, 48, generator=g).cuda(), torch.randn(3, T, generator=g).cuda(), torch.randn(3, 4, generator=g).cuda()
+        tgt = torch.randn(3, 2, 64, 48, generator=g).cuda()
+        if graphed:
+            losses.append(step(x, ts, md, tgt).clone())
+        else:
+            loss = crit(net(x, ts, md), tgt)["total"]
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            losses.append(loss.detach().clone())
+    if graphed:
+        assert step.graph is not None and step.calls == steps
+    # an EAGER eval forward after the last step must see the last step's weights (the replays change them behind Python's back)
+    net.eval()
+    with torch.no_grad():
+        ev = net(x, ts, md)
+    return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, ev
+
+
+@pytest.mark.parametrize("model_type,prec", [("unet", "bf16"), ("unet++", "bf16"), ("unet", "fp32")])
+def test_graphed_train_step_matches_eager(mau, model_type, prec):
+    """train_graph.GraphedTrainStep: forward + criterion + backward + fused AdamW captured ONCE into a hipGraph (call 3) and replayed
+    (calls 4..6) must give, bit for bit, the losses, parameters, BatchNorm buffers and the following eval output of the same six steps
+    launched kernel by kernel -- with a different batch every step (static input buffers refreshed by copies)."""
+    a = _train_n_steps(mau, model_type, prec, 6, graphed=False)
+    b = _train_n_steps(mau, model_type, prec, 6, graphed=True)
+    for la, lb in zip(a[0], b[0]):
+        assert torch.equal(la, lb), (a[0], b[0])
+    assert float(a[0][0]) != float(a[0][5])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+    assert torch.equal(a[2], b[2])
+
+
+def test_single_launch_reductions_and_multi_pack_are_bit_identical(mau, monkeypatch):
+    """Launch-tail fusions of round 3 against the forms they replace, same arithmetic in the same order: the single-launch slab
+    reductions (ticket: the last workgroup runs the second level; functional._FUSED_REDUCE) vs two launches, and the one-launch
+    multi-tensor weight pack (functional.PackGroup; MAU_PACK_MULTI) vs one launch per layer: two training steps, everything equal."""
+    from mau_amd import functional as F_
+    g = torch.Generator().manual_seed(71)
+    x, ts, md = torch.randn(4, 6, 96, 80, generator=g).cuda(), torch.randn(4, 10, generator=g).cuda(), torch.randn(4, 4, generator=g).cuda()
+    tgt = torch.randn(4, 2, 96, 80, generator=g).cuda()
+    res = []
+    for fused, multi in ((True, "1"), (False, "0")):
+        monkeypatch.setattr(F_, "_FUSED_REDUCE", fused)
+        monkeypatch.setenv("MAU_PACK_MULTI", multi)
+        torch.manual_seed(70)
+        net = mau.UrbanPredictor("unet", 6, 10, 16, 4, 16, 24, 2, base_filters=32, temporal_embeddings=False).cuda().set_precision("bf16").train()
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, fused=True)
+        outs = []
+        for _ in range(2):
+            out = net(x, ts, md)
+            loss = mau.compute_loss_mse(out, tgt)["total"]
+            loss.backward()
+            grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+            opt.step()
+            opt.zero_grad()
+            outs.append((out.detach().clone(), loss.detach().clone(), grads))
+        res.append((outs, {k: v.clone() for k, v in net.state_dict().items()}))
+    for (oa, la, ga), (ob, lb, gb) in zip(res[0][0], res[1][0]):
+        assert torch.equal(oa, ob) and torch.equal(la, lb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    # the tickets of the single-launch reductions are left zeroed by every launch
+    for tk in F_._TICKETS.values():
+        assert int(tk.abs().sum()) == 0
+
+
+def test_graphed_inference_survives_an_optimizer_step_elsewhere(mau):
+    """the frozen-session cache key contains the process-global optimizer-step generation, so ANY optimizer step (of
+    another model) makes the next eager frozen forward re-derive the packed weights and folded BatchNorm coefficients.  They are
+    refreshed IN PLACE (persistent buffers): a live GraphedInference graph, which holds their addresses, must keep replaying
+    correct results afterwards -- and after this model's own parameters change through ``mark_params_updated``."""
+    torch.manual_seed(80)
+    net = mau.UrbanPredictor("unet", 6, 10, 16, 4, 16, 24, 2, base_filters=16, temporal_embeddings=False).cuda().eval()
+    g = torch.Generator().manual_seed(81)
+    a = (torch.randn(1, 6, 64, 64, generator=g).cuda(), torch.randn(1, 10, generator=g).cuda(), torch.randn(1, 4, generator=g).cuda())
+    sess = mau.GraphedInference(net, *a)
+    with torch.no_grad():
+        ref = net(*a)
+    assert torch.equal(sess(*a), ref)
+    other = torch.nn.Linear(4, 4).cuda()
+    opt = torch.optim.SGD(other.parameters(), lr=0.1)
+    other(torch.randn(2, 4).cuda()).sum().backward()
+    opt.step()                                               # bumps the global generation
+    junk = [torch.randn(1 << 20, device="cuda") for _ in range(8)]   # churn the allocator: freed blocks would be reused by now
+    with torch.no_grad():
+        eager = net(*a)                                      # frozen eager forward: refreshes the copies (in place)
+    del junk
+    assert torch.equal(eager, ref)
+    assert torch.equal(sess(*a), ref)                        # the graph still reads valid, current buffers
+    # this model's parameters change behind a frozen session only through the documented door: the graph sees the new weights
+    with torch.no_grad():
+        for p in net.parameters():
+            p.data.mul_(1.01)
+    mau.mark_params_updated()
+    with torch.no_grad():
+        new = net(*a)
+    assert not torch.equal(new, ref)
+    assert torch.equal(sess(*a), new)
+
+
+def test_packs_follow_the_optimizer_and_sgd_tracks_the_oracle(mau):
+    """The stale-pack regression guard without AdamW's m / sqrt(v) amplification: five SGD-with-momentum steps track the
+    oracle to 2e-3 at EVERY step, and the packed weights used by step 1 differ from those of step 0."""
+    from mau_amd import functional as F_
+    flags = dict(temporal_embeddings=False, metadata_embeddings=True)
+    torch.manual_seed(21)
+    net = mau.UrbanPredictor("unet", 6, 10, 8, 4, 8, 12, 2, base_filters=8, **flags)
+    sd = R.clone_state({k: v.clone() for k, v in net.state_dict().items()}, requires_grad=True)
+    ref_opt = torch.optim.SGD([sd[k] for k in sd if R.is_param(k)], lr=0.05, momentum=0.9)
+    net = net.cuda().set_precision("fp32").train()
+    opt = torch.optim.SGD(net.parameters(), lr=0.05, momentum=0.9)
+    g = torch.Generator().manual_seed(22)
+    w = net.model.conv1_0.conv1.weight
+    packs = []
+    for step in range(5):
+        x, ts, md, tgt = torch.randn(2, 6, 32, 32, generator=g), torch.randn(2, 10, generator=g), torch.randn(2, 4, generator=g), torch.randn(2, 2, 32, 32, generator=g)
+        loss_ref, _, _ = R.train_step("unet", sd, ref_opt, x, ts, md, tgt, **flags)
+        out = net(x.cuda(), ts.cuda(), md.cuda())
+        packs.append(w._mau_pack[1].clone())
+        loss = mau.compute_loss_mse(out, tgt.cuda())["total"]
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        assert abs(float(loss) - float(loss_ref)) < 2e-3 * abs(float(loss_ref)), (step, float(loss), float(loss_ref))
+    assert not torch.equal(packs[0], packs[1]) and not torch.equal(packs[1], packs[2])
+    for k, p in net.named_parameters():
+        if sd[k].grad is not None or True:
+            e = rel_l2(p.detach().cpu(), sd[k].detach())
+            assert e < 2e-3, (k, e)
