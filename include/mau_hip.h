@@ -199,6 +199,36 @@ int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, cons
                           mau_stream_t stream);
 int mau_bn_bwd_rows(int64_t npix);
 
+/* ---- BatchNorm2d + ReLU fused with the streaming operator behind it (csrc/bn_fused.hip) ----
+ * An encoder block's output feeds nn.MaxPool2d(2,2) AND a skip connection (src/model.py:268-271 / :279-282).  Backward of its
+ * second BatchNorm without ever writing the incoming gradient da = dskip + maxpool_backward(dpl): both passes recompute it
+ * (the arg-max from a = relu(scale*y + shift) rounded to `dtype`, as mau_bn_relu_apply_pool stored it).  dpl (N,H/2,W/2) or
+ * dskip (N,H,W) may be NULL, not both.  slab / sums / count as mau_bn_relu_bwd_reduce / _apply; bit-identical to
+ * mau_maxpool2x2_bwd_add + mau_bn_relu_bwd_reduce + mau_bn_relu_bwd_apply. */
+int mau_pool_bn_bwd_reduce(const void* y, int ldy, const void* dpl, int lddpl, const void* dskip, int lddskip,
+                           const float* scale, const float* shift, const float* mean, const float* invstd, float* slab,
+                           int ldslab, int dtype, int N, int H, int W, int C, mau_stream_t stream);
+int mau_pool_bn_bwd_apply(const void* y, int ldy, const void* dpl, int lddpl, const void* dskip, int lddskip,
+                          const float* scale, const float* shift, const float* mean, const float* invstd,
+                          const double* sums, double count, void* dy, int lddy, int dtype, int N, int H, int W, int C,
+                          mau_stream_t stream);
+/* The final 1x1 conv + tanh (src/model.py:241,284-292) directly behind the last block's second BatchNorm (C <=
+ * mau_head_bn_max_channels()): out = head(relu(scale*y + shift)) from the RAW conv output y -- the activation is never
+ * written; backward in two passes over y: (1) BatchNorm partial sums (slab as mau_bn_relu_bwd_reduce) + the head's dW / db
+ * partials (head_slab as mau_head_bwd), (2) dy of the conv; da = W^T dz is recomputed from dout both times.  Bit-identical
+ * to mau_bn_relu_apply + mau_head_fwd / mau_head_bwd + mau_bn_relu_bwd_reduce + mau_bn_relu_bwd_apply. */
+int mau_head_bn_max_channels(void);
+int mau_head_bn_fwd(const void* y, int ldy, const float* scale, const float* shift, const float* w, const float* b, float* out,
+                    int tanh0, int dtype, int N, int HW, int C, int Co, mau_stream_t stream);
+int mau_head_bn_bwd_reduce(const void* y, int ldy, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, const float* w, const float* out, const float* dout, float* bn_slab,
+                           int ldslab, float* head_slab, int tanh0, int dtype, int N, int HW, int C, int Co,
+                           mau_stream_t stream);
+int mau_head_bn_bwd_apply(const void* y, int ldy, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const double* sums, double count, const float* w, const float* out,
+                          const float* dout, void* dy, int lddy, int tanh0, int dtype, int N, int HW, int C, int Co,
+                          mau_stream_t stream);
+
 /* ---- MaxPool2d(2,2) (src/model.py:57,218) -------------------------------- */
 int mau_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int N, int H, int W, int C,
                        mau_stream_t stream);
@@ -214,6 +244,11 @@ int mau_maxpool2x2_bwd_add(const void* x, int ldx, const void* dy, int lddy, con
 /* dst[..., choff:choff+C] = resize(src (N,h,w,C)) to (H,W); other channels of dst untouched. */
 int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst, int lddst, int choff,
                             int dtype, int N, int H, int W, int C, mau_stream_t stream);
+/* The same upsampling (h <= H, w <= W) reading the RAW conv output y of a block whose BatchNorm + ReLU has this resize as its
+ * only consumer (the U-Net's bottleneck and decoder blocks, src/model.py:279-282): relu(scale*y + shift), rounded to `dtype`,
+ * is formed on the four corners in registers; bit-identical to mau_bn_relu_apply + mau_resize_bilinear_fwd. */
+int mau_resize_bilinear_bn_fwd(const void* y, int ldy, int h, int w, const float* scale, const float* shift, void* dst,
+                               int lddst, int choff, int dtype, int N, int H, int W, int C, mau_stream_t stream);
 /* dsrc (N,h,w,C) = adjoint of the above applied to ddst[..., choff:choff+C] (gather form, no atomics). */
 int mau_resize_bilinear_bwd(const void* ddst, int ldddst, int choff, int H, int W, void* dsrc, int lddsrc,
                             int dtype, int N, int h, int w, int C, mau_stream_t stream);

@@ -61,6 +61,13 @@ PROTOTYPES = {
     "mau_bn_relu_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
     "mau_bn_relu_bwd_apply": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _d, _p, _i, _i, _i64, _i, _p]),
     "mau_bn_bwd_rows": (_i, [_i64]),
+    "mau_pool_bn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_pool_bn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _d, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_head_bn_max_channels": (_i, []),
+    "mau_head_bn_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_head_bn_bwd_reduce": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_head_bn_bwd_apply": (_i, [_p, _i, _p, _p, _p, _p, _p, _d, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_resize_bilinear_bn_fwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mau_maxpool2x2_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_maxpool2x2_bwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_maxpool2x2_bwd_add": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),

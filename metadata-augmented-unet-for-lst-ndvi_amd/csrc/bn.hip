@@ -419,8 +419,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __rest
   }
 }
 
-// Backward pass 1: block (64 channels x PIXB pixel slots); partial sums of dz and dz*xhat.
-constexpr int BWD_PIX_PER_BLOCK = 1024;
+// Backward pass 1: block (64 channels x 32 pixel slots over BWD_PIX_PER_BLOCK pixels); partial sums of dz and dz*xhat.
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ y,
@@ -461,7 +460,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
           const float act = fmaf(v[u].v[j], sc[j], sh[j]);
           const float dz = act > 0.f ? g[u].v[j] : 0.f;
           s1[j] += dz;
-          s2[j] += dz * ((v[u].v[j] - mu[j]) * is[j]);
+          s2[j] = fmaf(dz, (v[u].v[j] - mu[j]) * is[j], s2[j]);      // (explicit: the fused forms in bn_fused.hip must round alike)
         }
     }
     for (; p < p1; p += 32) {
@@ -472,7 +471,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
         const float act = fmaf(v.v[j], sc[j], sh[j]);
         const float dz = act > 0.f ? g.v[j] : 0.f;
         s1[j] += dz;
-        s2[j] += dz * ((v.v[j] - mu[j]) * is[j]);
+        s2[j] = fmaf(dz, (v.v[j] - mu[j]) * is[j], s2[j]);
       }
     }
   }

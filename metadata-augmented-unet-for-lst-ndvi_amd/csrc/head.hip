@@ -5,8 +5,7 @@
 
 namespace mau {
 
-constexpr int HEAD_MAX_CO = 4;
-constexpr int HEAD_PIX_PER_BLOCK = 512;
+// (HEAD_MAX_CO, HEAD_PIX_PER_BLOCK: mau_common.h)
 
 // 8 lanes per pixel: lane (pixel slot = tid/8, vector = tid%8) loads ONE 16-byte vector, so a wave reads
 // 8 pixels x 128 contiguous bytes per instruction; each lane keeps the weights of its 8 channels in

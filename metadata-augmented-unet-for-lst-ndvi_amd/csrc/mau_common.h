@@ -174,6 +174,13 @@ __device__ __forceinline__ float to_f(T x) {
   return (float)x;
 }
 
+// Pixel-block sizes of the slab reductions of bn.hip / head.hip and of their fused forms in bn_fused.hip: a workgroup reduces
+// BWD_PIX_PER_BLOCK consecutive pixels as (8 channel vectors) x (32 pixel slots, stride 32) -- the fused kernels keep this
+// geometry and per-thread order, so their sums are bit-identical to the two-pass forms they replace.
+constexpr int BWD_PIX_PER_BLOCK = 1024;
+constexpr int HEAD_MAX_CO = 4;
+constexpr int HEAD_PIX_PER_BLOCK = BWD_PIX_PER_BLOCK;
+
 // Shape of the device the calling thread is on, queried once per device: compute units and XCDs (an XCD of gfx950 has 32
 // active CUs and its own L2; SPX mode = 8 XCDs = 256 CUs, CPX partitions = 1).  Persistent grids, split counts and the
 // XCD-contiguous work-item orders are sized from this, not from literals.  (No device: the MI355X SPX shape.)

@@ -201,9 +201,14 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const T* __restrict__ s
 // 4 loads per ~4 stores instead of 4 per 1, a quarter of the workgroups: resize_fwd_kernel ran at 3.1-3.6 TB/s of its own
 // traffic where a plain fill of the destination reaches 6.9 (scripts/write_bw.py) -- it was bound by its one-output
 // threads, not by the write stream.
-template <typename T>
+// BN = true: `src` is the RAW output y of a conv whose BatchNorm + ReLU has this upsample as its only consumer (the U-Net's
+// decoder blocks and bottleneck, reference src/model.py:279-282): a = relu(scale*y + shift), rounded to T exactly as
+// bn_relu_apply would have stored it, is formed on the four corners in registers -- the activation is never written
+// (bit-identical to the two-pass form).
+template <typename T, bool BN>
 __global__ __launch_bounds__(256) void resize_fwd_cell_kernel(const T* __restrict__ src, int ldsrc, int h, int w, T* __restrict__ dst,
-                                                              int lddst, int choff, int H, int W, int C8) {
+                                                              int lddst, int choff, int H, int W, int C8, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int C) {
   const int nv = C8 >> 3;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= w * nv) return;
@@ -212,8 +217,18 @@ __global__ __launch_bounds__(256) void resize_fwd_cell_kernel(const T* __restric
   const float sy = ac_scale(h, H), sx = ac_scale(w, W);
   const int ys1 = ys + (ys < h - 1 ? 1 : 0), xs1 = xs + (xs < w - 1 ? 1 : 0);
   const T* b = src + (size_t)n * h * w * ldsrc + c;
-  const F8 v00 = load8<T>(b + ((size_t)ys * w + xs) * ldsrc), v01 = load8<T>(b + ((size_t)ys * w + xs1) * ldsrc);
-  const F8 v10 = load8<T>(b + ((size_t)ys1 * w + xs) * ldsrc), v11 = load8<T>(b + ((size_t)ys1 * w + xs1) * ldsrc);
+  F8 v00 = load8<T>(b + ((size_t)ys * w + xs) * ldsrc), v01 = load8<T>(b + ((size_t)ys * w + xs1) * ldsrc);
+  F8 v10 = load8<T>(b + ((size_t)ys1 * w + xs) * ldsrc), v11 = load8<T>(b + ((size_t)ys1 * w + xs1) * ldsrc);
+  if constexpr (BN) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float sc = c + e < C ? scale[c + e] : 0.f, sh = c + e < C ? shift[c + e] : 0.f;
+      v00.v[e] = (float)(T)fmaxf(fmaf(v00.v[e], sc, sh), 0.f);
+      v01.v[e] = (float)(T)fmaxf(fmaf(v01.v[e], sc, sh), 0.f);
+      v10.v[e] = (float)(T)fmaxf(fmaf(v10.v[e], sc, sh), 0.f);
+      v11.v[e] = (float)(T)fmaxf(fmaf(v11.v[e], sc, sh), 0.f);
+    }
+  }
   // destination rows / columns whose source index can be this cell (loose bounds, exact test below)
   int ja = 0, jb = H - 1, ka = 0, kb = W - 1;
   if (sy > 0.f) {
@@ -637,12 +652,25 @@ int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst,
   static const bool no_cell = getenv("MAU_RESIZE_NO_CELL") != nullptr;              // (A/B timing)
   if (h <= H && w <= W && h <= 65535 && !no_cell) {                                // upsampling: one thread per source cell
     dim3 gridc(ceil_div(w * (C8 / 8), 256), h, N);
-    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_fwd_cell_kernel<T>, gridc, dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, H, W, C8));
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((resize_fwd_cell_kernel<T, false>), gridc, dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, H, W, C8,
+                                         (const float*)nullptr, (const float*)nullptr, C));
     return check_launch("resize_fwd_cell_kernel");
   }
   dim3 grid(ceil_div(W * (C8 / 8), 256), H, N);
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(resize_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, H, W, C8));
   return check_launch("resize_fwd_kernel");
+}
+
+int mau_resize_bilinear_bn_fwd(const void* y, int ldy, int h, int w, const float* scale, const float* shift, void* dst, int lddst,
+                               int choff, int dtype, int N, int H, int W, int C, mau_stream_t stream) {
+  MAU_REQUIRE(y && dst && scale && shift && N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, "resize_bilinear_bn_fwd: bad arguments");
+  MAU_REQUIRE(h <= H && w <= W && h <= 65535 && N <= 65535, "resize_bilinear_bn_fwd: an upsampling (h <= H, w <= W), h and N within a grid dimension");
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(ldy % 8 == 0 && lddst % 8 == 0 && choff % 8 == 0 && ldy >= C8 && lddst >= choff + C8, "resize_bilinear_bn_fwd: bad ld/choff");
+  dim3 gridc(ceil_div(w * (C8 / 8), 256), h, N);
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((resize_fwd_cell_kernel<T, true>), gridc, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, h, w, (T*)dst, lddst,
+                                       choff, H, W, C8, scale, shift, C));
+  return check_launch("resize_fwd_cell_kernel<BN>");
 }
 
 int mau_resize_bilinear_bwd(const void* ddst, int ldddst, int choff, int H, int W, void* dsrc, int lddsrc, int dtype, int N,

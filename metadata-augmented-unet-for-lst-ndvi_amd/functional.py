@@ -291,6 +291,8 @@ class BNState:
     C1: int = 0                           # logical channels of the second tensor source (virtual concat), 0 = none
     pool: bool = False                    # also return maxpool2x2(output) (encoder blocks: skip + next level)
     out_view: object = None               # preallocated NHWC-ld view the activation is written into (U-Net++ row buffers)
+    head: object = None                   # None | True (tanh on channel 0 when out_channels == 2) | False (bare 1x1): return final(activation)
+    up_to: object = None                  # None | (H, W): return the bilinear (align_corners=True) resize of the activation
 
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
@@ -301,6 +303,7 @@ def _all_reduce_(t: torch.Tensor, st: BNState):
 
 _OVERLAP_WGRAD = os.environ.get("MAU_OVERLAP_WGRAD", "0") != "0"      # measured: ~1 % (profiles/r1), off by default
 _FUSED_REDUCE = os.environ.get("MAU_FUSED_REDUCE", "1") != "0"        # single-launch slab reductions (A/B switch; bit-identical)
+_FUSED_BN = os.environ.get("MAU_FUSED_BN", "1") != "0"                # BatchNorm passes fused with pool / head / upsample (A/B switch; bit-identical)
 _SIDE_STREAMS = {}
 
 
@@ -324,10 +327,19 @@ def _conv_fwd(x, x1, st, emb, emb_ws, E, wpk, bias, post, y, Cout, slab, code, N
 class ConvBNReLU(torch.autograd.Function):
     """relu(bn(conv3x3(cat([x, x1, broadcast(emb)], 1)))) -- one half of VGGBlock.forward (src/model.py:18-21) with the
     decoder's channel concat (src/model.py:279-282) and fuse_embeddings (:248-259) as loader sources, never materialised.
-    With ``st.pool`` the second output is nn.MaxPool2d(2,2) of the first (src/model.py:268-271), written in the same pass."""
+
+    What happens to the activation decides the variant (``BNState``), so that a full-resolution tensor is never written just
+    to be read once by a streaming operator:
+      * ``pool``  -- also returns nn.MaxPool2d(2,2) of the activation (src/model.py:268-271), written in the same pass; the
+                     backward recomputes "skip gradient + pool gradient" inside both BatchNorm passes (no ``da`` tensor);
+      * ``head``  -- returns final(activation) with tanh on channel 0 (src/model.py:284-292) instead of the activation: the
+                     1x1 head reads the raw conv output and applies BatchNorm + ReLU on the fly, forward and backward;
+      * ``up_to`` -- returns up(activation) (bilinear x2, align_corners=True, src/model.py:219,279-282) instead of the
+                     activation: the resize applies BatchNorm + ReLU to the four corners it loads.
+    ``MAU_FUSED_BN=0`` runs the same variants through the separate kernels (bit-identical; the A/B and test switch)."""
 
     @staticmethod
-    def forward(ctx, x, x1, emb, weight, bias, gamma, beta, rmean, rvar, nbt, st: BNState):
+    def forward(ctx, x, x1, emb, weight, bias, gamma, beta, rmean, rvar, nbt, hw, hb, st: BNState):
         _require_cuda(x, "conv3x3")
         x = _as_nhwc(x)
         if x1 is not None:
@@ -351,16 +363,36 @@ class ConvBNReLU(torch.autograd.Function):
         dst = st.out_view                               # where the activation goes: a slot of a row buffer, or a fresh tensor
         if dst is not None and (tuple(dst.shape) != (N, H, W, ldy) or dst.dtype != x.dtype or Cout % 64 != 0):
             raise RuntimeError("conv3x3: out_view must be an (N,H,W,Cout) NHWC-ld view of the activation dtype with Cout % 64 == 0")
-        y = dst if (inference and dst is not None) else torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
+        if sum((st.pool, st.head is not None, st.up_to is not None)) > 1 or ((st.head is not None or st.up_to is not None) and dst is not None):
+            raise RuntimeError("conv3x3: pool / head / up_to are exclusive, and head / up_to write no activation (no out_view)")
+        Co = tanh0 = 0
+        w2 = None
+        if st.head is not None:
+            Co = hw.shape[0]
+            tanh0 = 1 if (Co == 2 and st.head) else 0
+            w2 = hw.detach().reshape(Co, Cout).contiguous().float()
 
         def pooled_of(a):
             pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
             call("mau_maxpool2x2_fwd", a.data_ptr(), _ld(a), pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
             return pl
 
+        def head_of(a):                                 # final 1x1 conv (+ tanh on channel 0) of a materialised activation
+            out = torch.empty((N, Co, H, W), **f32)
+            call("mau_head_fwd", a.data_ptr(), _ld(a), w2.data_ptr(), hb.detach().data_ptr(), out.data_ptr(), tanh0, code, N, H * W,
+                 Cout, Co, stream)
+            return out
+
+        def up_of(a):                                   # bilinear resize of a materialised activation
+            Hu, Wu = st.up_to
+            up = torch.empty((N, Hu, Wu, ldy), dtype=x.dtype, device=dev)
+            call("mau_resize_bilinear_fwd", a.data_ptr(), _ld(a), H, W, up.data_ptr(), ldy, 0, code, N, Hu, Wu, Cout, stream)
+            return up
+
         if inference:
             # eval-mode BN + ReLU are a fixed per-channel affine map -> folded into the conv epilogue.  In a frozen
             # session (UrbanPredictor.freeze_inference) the packed weights and the folded coefficients are computed once.
+            y = dst if dst is not None else torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
             fz = st.frozen if st.frozen is not None else {}
             fkey = (_GENERATION[0], weight._version, gamma._version, rmean._version, rvar._version)
             if "wf" not in fz or fz["wf"].dtype != x.dtype or fz.get("key") != fkey:
@@ -375,12 +407,21 @@ class ConvBNReLU(torch.autograd.Function):
                 call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                      st.eps, fz["scale"].data_ptr(), fz["shift"].data_ptr(), None, None, Cout, stream)
             _conv_fwd(x, x1, st, emb, emb_ws, E, fz["wf"], bias, (fz["scale"], fz["shift"]), y, Cout, None, code, N, H, W, stream)
+            if st.head is not None:
+                out = head_of(y)
+                ctx.mark_non_differentiable(out)
+                return out
+            if st.up_to is not None:
+                up = up_of(y)
+                ctx.mark_non_differentiable(up)
+                return up
             ctx.mark_non_differentiable(y)
             if st.pool:
                 pl = pooled_of(y)
                 ctx.mark_non_differentiable(pl)
                 return y, pl
             return y
+        y = torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
         need_dx = needs[0] or (x1 is not None and needs[1]) or (E > 0 and needs[2])
         wf, wd = pack_conv_weights(weight, code, forward=True, dgrad=st.grad_enabled and need_dx)
         scale, shift = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
@@ -414,29 +455,56 @@ class ConvBNReLU(torch.autograd.Function):
             call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                  st.eps, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cout, stream)
             _conv_fwd(x, x1, st, emb, emb_ws, E, wf, bias, None, y, Cout, None, code, N, H, W, stream)
-        a = dst if dst is not None else torch.empty_like(y)
-        lda = _ld(a)
-        pl = None
-        if st.pool and H >= 2 and W >= 2:
-            pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
-            call("mau_bn_relu_apply_pool", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), lda,
-                 pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
+
+        # ---- the activation stage ----
+        fused = _FUSED_BN
+        fuse_head = fused and st.head is not None and Cout <= lib.mau_head_bn_max_channels()
+        fuse_up = fused and st.up_to is not None and H <= st.up_to[0] and W <= st.up_to[1]
+        a = pl = out = up = None
+        if fuse_head:                                    # the head reads y and applies BatchNorm + ReLU on the fly: no activation tensor
+            out = torch.empty((N, Co, H, W), **f32)
+            call("mau_head_bn_fwd", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), w2.data_ptr(), hb.detach().data_ptr(),
+                 out.data_ptr(), tanh0, code, N, H * W, Cout, Co, stream)
+        elif fuse_up:                                    # the resize applies BatchNorm + ReLU to the corners it loads
+            Hu, Wu = st.up_to
+            up = torch.empty((N, Hu, Wu, ldy), dtype=x.dtype, device=dev)
+            call("mau_resize_bilinear_bn_fwd", y.data_ptr(), ldy, H, W, scale.data_ptr(), shift.data_ptr(), up.data_ptr(), ldy, 0, code,
+                 N, Hu, Wu, Cout, stream)
         else:
-            call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), lda, code,
-                 npix, Cout, stream)
+            a = dst if dst is not None else torch.empty_like(y)
+            lda = _ld(a)
+            if st.pool and H >= 2 and W >= 2:
+                pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
+                call("mau_bn_relu_apply_pool", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), lda,
+                     pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
+            else:
+                call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), lda, code,
+                     npix, Cout, stream)
+            if st.head is not None:
+                out = head_of(a)
+            elif st.up_to is not None:
+                up = up_of(a)
         ctx.st = st
         ctx.E = E
         ctx.C1 = C1
         ctx.wd = wd                           # data-gradient pack of THIS forward's weights
         ctx.pooled = pl is not None
-        ctx.save_for_backward(x, x1, emb, weight, y, scale, shift, mean, invstd, a if pl is not None else None)
+        ctx.head = (Co, tanh0, tuple(hw.shape), fuse_head) if st.head is not None else None
+        ctx.up = (st.up_to, fuse_up) if st.up_to is not None else None
+        # the activation is saved only where the backward still reads it: the unfused pool (arg-max) and the unfused head (dW)
+        keep_a = a if ((pl is not None and not fused) or (st.head is not None and not fuse_head)) else None
+        ctx.save_for_backward(x, x1, emb, weight, y, scale, shift, mean, invstd, keep_a, w2, out)
+        if st.head is not None:
+            return out
+        if st.up_to is not None:
+            return up
         if st.pool:
             return a, pl
         return a
 
     @staticmethod
     def backward(ctx, da, dpl=None):
-        x, x1, emb, weight, y, scale, shift, mean, invstd, a = ctx.saved_tensors
+        x, x1, emb, weight, y, scale, shift, mean, invstd, a, w2, out = ctx.saved_tensors
         st: BNState = ctx.st
         E, C1 = ctx.E, ctx.C1
         N, H, W, ldy = y.shape
@@ -447,44 +515,103 @@ class ConvBNReLU(torch.autograd.Function):
         stream = _stream()
         f32 = dict(dtype=torch.float32, device=dev)
         needs = ctx.needs_input_grad
-        if ctx.pooled and dpl is not None:
-            # the block's output fed the pool AND the skip connection: one pass adds the two gradients (PoolSkip's job)
-            dpl = _as_nhwc(dpl)
-            dsum = torch.empty((N, H, W, ldy), dtype=y.dtype, device=dev)
-            if da is None:
-                call("mau_maxpool2x2_bwd", a.data_ptr(), _ld(a), dpl.data_ptr(), _ld(dpl), dsum.data_ptr(), ldy, code, N, H, W, Cout, stream)
-            else:
-                da = _as_nhwc(da)
-                call("mau_maxpool2x2_bwd_add", a.data_ptr(), _ld(a), dpl.data_ptr(), _ld(dpl), da.data_ptr(), _ld(da),
-                     dsum.data_ptr(), ldy, code, N, H, W, Cout, stream)
-            da = dsum
-        elif da is None:
-            da = torch.zeros((N, H, W, ldy), dtype=y.dtype, device=dev)
-        da = _as_nhwc(da)
-        # --- BN + ReLU backward: two passes over (da, y) ---
+        sync = st.training and st.group is not None
         rows = lib.mau_bn_bwd_rows(npix)
         slab = torch.empty((rows, 2 * Cout), **f32)
-        call("mau_bn_relu_bwd_reduce", da.data_ptr(), _ld(da), y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(),
-             mean.data_ptr(), invstd.data_ptr(), slab.data_ptr(), Cout, code, npix, Cout, stream)
         sums = torch.empty(2 * Cout + 1, dtype=torch.float64, device=dev)
-        ws = torch.empty(lib.mau_reduce_rows_ws_elems(rows, 2 * Cout), dtype=torch.float64, device=dev)
         g32 = torch.empty(2 * Cout, **f32)                   # [dbeta | dgamma]: the LOCAL sums, rounded to fp32 by the reducer
-        sync = st.training and st.group is not None
-        call("mau_reduce_rows_f64_f32", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), g32.data_ptr(), ws.data_ptr(),
-             _tickets(dev).data_ptr() if (_FUSED_REDUCE or sync) else None, float(npix) if sync else 0.0, stream)
+        dy = torch.empty_like(y)
+        dhw = dhb = None
+        cptrs = (scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
+
+        def finish_sums():
+            """slab -> sums (fp64) + g32 (fp32), one launch; data parallel: all-reduce with the pixel count appended.
+            Returns (sums for the apply pass, count argument)."""
+            ws = torch.empty(lib.mau_reduce_rows_ws_elems(rows, 2 * Cout), dtype=torch.float64, device=dev)
+            call("mau_reduce_rows_f64_f32", slab.data_ptr(), rows, 2 * Cout, 2 * Cout, sums.data_ptr(), g32.data_ptr(), ws.data_ptr(),
+                 _tickets(dev).data_ptr() if (_FUSED_REDUCE or sync) else None, float(npix) if sync else 0.0, stream)
+            if not st.training:
+                return torch.zeros_like(sums), float(npix)       # eval-mode BN is a fixed affine map
+            if sync:                                             # the global count travels with the sums (see forward)
+                _all_reduce_(sums, st)
+                return sums, 0.0
+            return sums, float(npix)
+
+        fused_pool = ctx.pooled and dpl is not None and _FUSED_BN and a is None
+        if ctx.head is not None and ctx.head[3]:
+            # ---- head + BatchNorm backward, two passes over y: da = W_head^T dz is recomputed from dout in both ----
+            Co, tanh0, hshape, _ = ctx.head
+            dout = da.contiguous().float()
+            hrows, rowlen = lib.mau_head_bwd_rows(N, H * W), lib.mau_head_bwd_rowlen(Cout, Co)
+            hslab = torch.empty((hrows, rowlen), **f32)
+            call("mau_head_bn_bwd_reduce", y.data_ptr(), ldy, *cptrs, w2.data_ptr(), out.data_ptr(), dout.data_ptr(), slab.data_ptr(), Cout,
+                 hslab.data_ptr(), tanh0, code, N, H * W, Cout, Co, stream)
+            sums_apply, count = finish_sums()
+            red = torch.empty(rowlen, **f32)
+            hws = torch.empty(lib.mau_reduce_rows_ws_elems(hrows, rowlen), dtype=torch.float64, device=dev)
+            call("mau_reduce_rows_f32", hslab.data_ptr(), hrows, rowlen, rowlen, red.data_ptr(), hws.data_ptr(),
+                 _tickets(dev).data_ptr() if _FUSED_REDUCE else None, stream)
+            red = red.view(Co, pad8(Cout) + 8)
+            dhw = red[:, :Cout].reshape(hshape).contiguous()
+            dhb = red[:, pad8(Cout)].contiguous()
+            call("mau_head_bn_bwd_apply", y.data_ptr(), ldy, *cptrs, sums_apply.data_ptr(), count, w2.data_ptr(), out.data_ptr(),
+                 dout.data_ptr(), dy.data_ptr(), ldy, tanh0, code, N, H * W, Cout, Co, stream)
+        elif fused_pool:
+            # ---- pool + skip + BatchNorm backward, two passes over (y, dpl, dskip): no da tensor ----
+            dpl = _as_nhwc(dpl)
+            dsk = _as_nhwc(da) if da is not None else None
+            pargs = (y.data_ptr(), ldy, dpl.data_ptr(), _ld(dpl), dsk.data_ptr() if dsk is not None else None, _ld(dsk) if dsk is not None else 0)
+            call("mau_pool_bn_bwd_reduce", *pargs, *cptrs, slab.data_ptr(), Cout, code, N, H, W, Cout, stream)
+            sums_apply, count = finish_sums()
+            call("mau_pool_bn_bwd_apply", *pargs, *cptrs, sums_apply.data_ptr(), count, dy.data_ptr(), ldy, code, N, H, W, Cout, stream)
+        else:
+            if ctx.head is not None:
+                # unfused head: da, dW, db from the saved activation
+                Co, tanh0, hshape, _ = ctx.head
+                dout = da.contiguous().float()
+                da = torch.empty((N, H, W, ldy), dtype=y.dtype, device=dev)
+                hrows, rowlen = lib.mau_head_bwd_rows(N, H * W), lib.mau_head_bwd_rowlen(Cout, Co)
+                hslab = torch.empty((hrows, rowlen), **f32)
+                call("mau_head_bwd", a.data_ptr(), _ld(a), w2.data_ptr(), out.data_ptr(), dout.data_ptr(), da.data_ptr(), ldy,
+                     hslab.data_ptr(), tanh0, code, N, H * W, Cout, Co, stream)
+                red = torch.empty(rowlen, **f32)
+                hws = torch.empty(lib.mau_reduce_rows_ws_elems(hrows, rowlen), dtype=torch.float64, device=dev)
+                call("mau_reduce_rows_f32", hslab.data_ptr(), hrows, rowlen, rowlen, red.data_ptr(), hws.data_ptr(),
+                     _tickets(dev).data_ptr() if _FUSED_REDUCE else None, stream)
+                red = red.view(Co, pad8(Cout) + 8)
+                dhw = red[:, :Cout].reshape(hshape).contiguous()
+                dhb = red[:, pad8(Cout)].contiguous()
+            elif ctx.up is not None:
+                # the upsample's adjoint produces da (its forward read y through BatchNorm + ReLU, or the activation)
+                (Hu, Wu), _ = ctx.up
+                g = _as_nhwc(da)
+                da = torch.empty((N, H, W, ldy), dtype=y.dtype, device=dev)
+                call("mau_resize_bilinear_bwd", g.data_ptr(), _ld(g), 0, Hu, Wu, da.data_ptr(), ldy, code, N, H, W, Cout, stream)
+            elif ctx.pooled and dpl is not None:
+                # the block's output fed the pool AND the skip connection: one pass adds the two gradients (PoolSkip's job)
+                dpl = _as_nhwc(dpl)
+                act = a
+                if act is None:                          # (fused build, but this backward runs unfused: recompute the activation)
+                    act = torch.empty_like(y)
+                    call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), act.data_ptr(), ldy, code, npix, Cout, stream)
+                dsum = torch.empty((N, H, W, ldy), dtype=y.dtype, device=dev)
+                if da is None:
+                    call("mau_maxpool2x2_bwd", act.data_ptr(), _ld(act), dpl.data_ptr(), _ld(dpl), dsum.data_ptr(), ldy, code, N, H, W, Cout, stream)
+                else:
+                    da = _as_nhwc(da)
+                    call("mau_maxpool2x2_bwd_add", act.data_ptr(), _ld(act), dpl.data_ptr(), _ld(dpl), da.data_ptr(), _ld(da),
+                         dsum.data_ptr(), ldy, code, N, H, W, Cout, stream)
+                da = dsum
+            elif da is None:
+                da = torch.zeros((N, H, W, ldy), dtype=y.dtype, device=dev)
+            da = _as_nhwc(da)
+            # --- BN + ReLU backward: two passes over (da, y) ---
+            call("mau_bn_relu_bwd_reduce", da.data_ptr(), _ld(da), y.data_ptr(), ldy, *cptrs, slab.data_ptr(), Cout, code, npix, Cout, stream)
+            sums_apply, count = finish_sums()
+            call("mau_bn_relu_bwd_apply", da.data_ptr(), _ld(da), y.data_ptr(), ldy, *cptrs, sums_apply.data_ptr(), count, dy.data_ptr(), ldy,
+                 code, npix, Cout, stream)
         dgamma = g32[Cout:]
         dbeta = g32[:Cout]
-        if st.training:
-            if st.group is not None:                         # the global count travels with the sums (see forward)
-                _all_reduce_(sums, st)
-                sums_apply, count = sums, 0.0
-            else:
-                sums_apply, count = sums, float(npix)
-        else:
-            sums_apply, count = torch.zeros_like(sums), float(npix)     # eval-mode BN is a fixed affine map
-        dy = torch.empty_like(y)
-        call("mau_bn_relu_bwd_apply", da.data_ptr(), _ld(da), y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(),
-             mean.data_ptr(), invstd.data_ptr(), sums_apply.data_ptr(), count, dy.data_ptr(), ldy, code, npix, Cout, stream)
         # --- weight gradient: independent of the data gradient given dy ---
         dw = None
         need_dx = needs[0] or (x1 is not None and needs[1]) or (E and needs[2])
@@ -537,7 +664,7 @@ class ConvBNReLU(torch.autograd.Function):
             else:
                 # eval-mode BN is the fixed affine map z = scale*y + shift: d/dbias = sum(dy) = scale * sum(dz)
                 dbias = scale * dbeta
-        return dx, dx1, demb, dw, dbias, dgamma, dbeta, None, None, None, None
+        return dx, dx1, demb, dw, dbias, dgamma, dbeta, None, None, None, dhw, dhb, None
 
 
 # --------------------------------------------------------------------------- #

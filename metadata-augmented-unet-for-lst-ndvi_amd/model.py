@@ -76,26 +76,34 @@ class VGGBlock(nn.Module):
         if self._frozen is not None:
             self._frozen = [{}, {}]
 
-    def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d, x1: Optional[Act] = None, pool: bool = False, out_view=None):
+    def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d, x1: Optional[Act] = None, pool: bool = False, out_view=None,
+              head: Optional[nn.Conv2d] = None, head_act: bool = True, up_to=None):
         rt = self._rt or _Runtime()
         if self._group is not None and getattr(conv.weight, "_mau_group", None) is not self._group:
             self._group.add(conv.weight)          # (a deep copy of the network carries new Parameter objects)
         st = BNState(training=self.training and bn.training, C0=x.C, momentum=bn.momentum, eps=bn.eps,
                      group=rt.group, world=rt.world, grad_enabled=torch.is_grad_enabled(),
                      frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1],
-                     C1=0 if x1 is None else x1.C, pool=pool, out_view=out_view)
+                     C1=0 if x1 is None else x1.C, pool=pool, out_view=out_view,
+                     head=None if head is None else bool(head_act), up_to=up_to)
         t = F_.ConvBNReLU.apply(x.t, None if x1 is None else x1.t, emb, conv.weight, conv.bias, bn.weight, bn.bias,
-                                bn.running_mean, bn.running_var, bn.num_batches_tracked, st)
+                                bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                None if head is None else head.weight, None if head is None else head.bias, st)
+        if head is not None:
+            return t                                # (N, out_channels, H, W) fp32: the module's output
         if pool:
             return Act(t[0], conv.out_channels), Act(t[1], conv.out_channels)
         return Act(t, conv.out_channels)
 
-    def forward(self, x: Act, emb: Optional[torch.Tensor] = None, x1: Optional[Act] = None, pool: bool = False, out_view=None):
+    def forward(self, x: Act, emb: Optional[torch.Tensor] = None, x1: Optional[Act] = None, pool: bool = False, out_view=None,
+                head: Optional[nn.Conv2d] = None, head_act: bool = True, up_to=None):
         """``x1``: second input tensor, channel-concatenated after ``x`` by the conv loader (never materialised);
         ``pool=True`` returns ``(block output, maxpool2x2(block output))``; ``out_view``: preallocated NHWC view the block's
-        output is written into (a slot of a U-Net++ row buffer)."""
+        output is written into (a slot of a U-Net++ row buffer); ``head``: the network's final 1x1 conv -- the block returns
+        ``final(block output)`` (tanh on channel 0 when ``head_act`` and out_channels == 2) and the block output itself is never
+        written; ``up_to=(H, W)``: the block returns the bilinear (align_corners=True) resize of its output instead of it."""
         x = self._half(x, emb, self.conv1, self.bn1, x1)
-        return self._half(x, None, self.conv2, self.bn2, None, pool, out_view)
+        return self._half(x, None, self.conv2, self.bn2, None, pool, out_view, head, head_act, up_to)
 
 
 _SIDE_STREAMS = {}
@@ -273,23 +281,33 @@ class UrbanPredictor_unet(_NetBase):
         self.final = nn.Conv2d(nb_filter[0], out_channels, kernel_size=1)
         self._bind_runtime()
 
-    def _dec(self, block: VGGBlock, skip: Act, low: Act) -> Act:
+    def _up_target(self, skip: Act, low_hw):
+        """(H, W) when ``up(low)`` for this skip can be produced by the block that computes ``low`` (its only consumer is the
+        upsample: bottleneck and decoder blocks, src/model.py:279-282): the virtual concat is in use and the x2 upsample
+        lands exactly on the skip's size (no second resize, src/model.py:243-246); else None."""
+        if self._fusable(skip) and (2 * low_hw[0], 2 * low_hw[1]) == (skip.H, skip.W):
+            return (skip.H, skip.W)
+        return None
+
+    def _dec(self, block: VGGBlock, skip: Act, low: Act, low_is_up: bool = False, **kw):
         # block(cat([skip, _upsample_match(up(low), skip)], 1)), src/model.py:243-246,279-282
+        if low_is_up:                                    # ``low`` already is up(low): produced by the block below (VGGBlock up_to)
+            return block(skip, None, low, **kw)
         if self._fusable(skip):
             up = Act(F_.UpsampleTo.apply(low.t, low.C, True, skip.H, skip.W), low.C)
-            return block(skip, None, up)                 # [skip, up] are two sources of the conv loader: no concat buffer
+            return block(skip, None, up, **kw)           # [skip, up] are two sources of the conv loader: no concat buffer
         t = F_.ConcatUp.apply(low.t, low.C, True, (skip.C,), skip.t)
-        return block(Act(t, skip.C + low.C))
+        return block(Act(t, skip.C + low.C), **kw)
 
-    def _fused_block(self, block: VGGBlock, x: Act, embs: List[torch.Tensor]) -> Act:
+    def _fused_block(self, block: VGGBlock, x: Act, embs: List[torch.Tensor], **kw) -> Act:
         """conv4_0(fuse_embeddings(x, ...)) with the broadcast folded into the conv loader (src/model.py:248-259)."""
         if not embs:
-            return block(x)
+            return block(x, **kw)
         emb = embs[0] if len(embs) == 1 else torch.cat(embs, dim=1)     # order [temporal, meta]
         if x.C % 8 == 0 and emb.shape[1] % 8 == 0:
-            return block(x, emb.float())
+            return block(x, emb.float(), **kw)
         # channel counts that do not fit the 8-channel vector granularity: materialise the concat
-        return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]))
+        return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]), **kw)
 
     def forward(self, maps, temp_series, metadata):
         join = None
@@ -305,13 +323,19 @@ class UrbanPredictor_unet(_NetBase):
         x4_0, x3_0 = self._block_pool(self.conv3_0, p)
         if join is not None:
             join()
-        x4_0 = self._fused_block(self.conv4_0, x4_0, [e for e in (temporal_emb, meta_emb) if e is not None])
-        x3_1 = self._dec(self.conv3_1, x3_0, x4_0)
-        x2_1 = self._dec(self.conv2_1, x2_0, x3_1)
-        x1_1 = self._dec(self.conv1_1, x1_0, x2_1)
-        x0_1 = self._dec(self.conv0_1, x0_0, x1_1)
-        return self._head(x0_1)
-
+        # A bottleneck / decoder block's output is read ONLY by the x2 upsample of the level above: the block returns
+        # up(output) directly (BatchNorm + ReLU applied by the resize kernel; the low-resolution activation is never written)
+        embs = [e for e in (temporal_emb, meta_emb) if e is not None]
+        skips = (x3_0, x2_0, x1_0, x0_0)
+        blocks = (self.conv3_1, self.conv2_1, self.conv1_1, self.conv0_1)
+        tgt = self._up_target(skips[0], (x4_0.H, x4_0.W))
+        low = self._fused_block(self.conv4_0, x4_0, embs, up_to=tgt)
+        for i, (blk, skip) in enumerate(zip(blocks, skips)):
+            was_up, h, w = tgt is not None, skip.H, skip.W
+            if i == 3:                                   # the last block feeds the 1x1 head: it returns final(output)
+                return self._dec(blk, skip, low, was_up, head=self.final)
+            tgt = self._up_target(skips[i + 1], (h, w))
+            low = self._dec(blk, skip, low, was_up, up_to=tgt)
 
     @torch.no_grad()
     def forward_metadata_sweep(self, maps, temp_series, metadata):
@@ -386,7 +410,7 @@ class UrbanPredictor_unetpp(_NetBase):
             self.final = nn.Conv2d(nb[0], out_channels, kernel_size=1)
         self._bind_runtime()
 
-    def _node(self, block: VGGBlock, skips: List[Act], below: Act, emb: torch.Tensor, out_view=None, rows: bool = False) -> Act:
+    def _node(self, block: VGGBlock, skips: List[Act], below: Act, emb: torch.Tensor, out_view=None, rows: bool = False, head=None):
         # cat([skips..., _upsample_match(below, (H, W)), emb_map], 1), src/model.py:111-121,136-177
         # rows: the skips sit side by side in one row buffer (an argument, not module state: forward stays re-entrant)
         fused_emb = (sum(s.C for s in skips) + below.C) % 8 == 0 and emb.shape[1] % 8 == 0
@@ -396,12 +420,12 @@ class UrbanPredictor_unetpp(_NetBase):
             # already sit side by side (RowPrefix: a view, no copy)
             first = skips[0] if len(skips) == 1 else Act(F_.RowPrefix.apply(skips[0].C, *[s.t for s in skips]), sum(s.C for s in skips))
             up = Act(F_.UpsampleTo.apply(below.t, below.C, False, skips[0].H, skips[0].W), below.C)
-            return block(first, emb, up, out_view=out_view)
+            return block(first, emb, up, out_view=out_view, head=head)
         t = F_.ConcatUp.apply(below.t, below.C, False, tuple(s.C for s in skips), *[s.t for s in skips])
         x = Act(t, sum(s.C for s in skips) + below.C)
         if x.C % 8 == 0 and emb.shape[1] % 8 == 0:
-            return block(x, emb, out_view=out_view)       # broadcast embedding folded into the conv loader
-        return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]), out_view=out_view)
+            return block(x, emb, out_view=out_view, head=head)       # broadcast embedding folded into the conv loader
+        return block(Act(F_.BcastCat.apply(x.t, x.C, emb), x.C + emb.shape[1]), out_view=out_view, head=head)
 
     def forward(self, maps, temp_series, metadata):
         join = None
@@ -448,11 +472,12 @@ class UrbanPredictor_unetpp(_NetBase):
         x3_1 = self._node(self.conv3_1, [x3_0], x4_0, emb, rows=use_rows)
         x2_2 = self._node(self.conv2_2, [x2_0, x2_1], x3_1, emb, rows=use_rows)
         x1_3 = self._node(self.conv1_3, [x1_0, x1_1, x1_2], x2_2, emb, rows=use_rows)
-        x0_4 = self._node(self.conv0_4, [x0_0, x0_1, x0_2, x0_3], x1_3, emb, rows=use_rows)
         if self.deep_supervision:
+            x0_4 = self._node(self.conv0_4, [x0_0, x0_1, x0_2, x0_3], x1_3, emb, rows=use_rows)
             return [F_.Head.apply(a.t, a.C, f.weight, f.bias, False)          # bare 1x1 convs, no tanh (src/model.py:180-185)
                     for a, f in ((x0_1, self.final1), (x0_2, self.final2), (x0_3, self.final3), (x0_4, self.final4))]
-        return self._head(x0_4)
+        # x^{0,4} is read only by the 1x1 head: the block returns final(x^{0,4}) (src/model.py:187-193)
+        return self._node(self.conv0_4, [x0_0, x0_1, x0_2, x0_3], x1_3, emb, rows=use_rows, head=self.final)
 
 
 class UrbanPredictor(nn.Module):

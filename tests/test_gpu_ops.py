@@ -327,7 +327,7 @@ def test_g3_fused_embedding_broadcast(mau, prec):
     # identity BatchNorm in eval mode (mean 0, var 1-eps) isolates the convolution: a = relu(conv + bias)
     st = F_.BNState(training=False, C0=sp.C, eps=0.0)
     a = F_.ConvBNReLU.apply(sp.t, None, emb, w, b, ones.clone().requires_grad_(True), zeros.clone().requires_grad_(True),
-                            zeros.clone(), ones.clone(), None, st)
+                            zeros.clone(), ones.clone(), None, None, None, st)
     yref = t(d["y"])
     assert err(from_act(mau, F_.Act(a, Cout)), torch.relu(yref)) < tol
     # gradient: upstream dy masked by relu on the reference side
@@ -552,3 +552,41 @@ def test_conv3x3_big_tile_variants_exact(m16):
     env = dict(os.environ, MAU_CONV_M16=m16)
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "conv_big_tile_check.py")], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "ALL OK" in p.stdout, (p.stdout[-3000:], p.stderr[-2000:])
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("model_type,size,base", [("unet", (64, 48), 16), ("unet", (62, 50), 16), ("unet++", (64, 64), 64), ("unet", (32, 32), 64)])
+def test_fused_bn_backward_matches_unfused(mau, model_type, size, base, prec, monkeypatch):
+    """BatchNorm + ReLU fused with the operator on its far side (csrc/bn_fused.hip, resize_fwd_cell_kernel<BN>): the encoder blocks'
+    pool + skip backward without a ``da`` tensor, the 1x1 head reading the raw conv output forward and backward, the decoder /
+    bottleneck blocks returning up(output).  The fused kernels recompute exactly what the separate kernels store (rounded to the
+    activation type) and keep the reductions' geometry and order: outputs, loss, EVERY gradient and the BatchNorm buffers of a
+    training step must equal the unfused path (MAU_FUSED_BN=0 semantics) bit for bit -- even (x2 upsample exact) and odd sizes
+    (pool windows that do not cover the last row / column, second resize), 64-channel heads and narrow ones, all three dtypes."""
+    from mau_amd import functional as F_
+    if prec == "fp32" and model_type == "unet++":
+        pytest.skip("same code path as the U-Net in fp32")
+    flags = {} if model_type == "unet++" else dict(temporal_embeddings=False, metadata_embeddings=True)
+    g = torch.Generator().manual_seed(91)
+    Hh, Ww = size
+    x, ts, md = torch.randn(2, 6, Hh, Ww, generator=g).cuda(), torch.randn(2, 10, generator=g).cuda(), torch.randn(2, 4, generator=g).cuda()
+    tgt = torch.randn(2, 2, Hh, Ww, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(F_, "_FUSED_BN", fused)
+        torch.manual_seed(90)
+        net = mau.UrbanPredictor(model_type, 6, 10, 16, 4, 16, 24, 2, base_filters=base, **flags).cuda().set_precision(prec).train()
+        out = net(x, ts, md)
+        loss = mau.compute_loss_mse(out, tgt)["total"]
+        loss.backward()
+        res.append((out.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}))
+        net.eval()
+        with torch.no_grad():
+            res[-1] += (net(x, ts, md),)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][4], res[1][4])
+    assert res[0][2].keys() == res[1][2].keys()
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    for k in res[0][3]:
+        assert torch.equal(res[0][3][k], res[1][3][k]), k
