@@ -184,8 +184,12 @@ int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* s
                       int dtype, int64_t npix, int C, mau_stream_t stream);
 /* a = relu(scale*y + shift) AND pooled (N,H/2,W/2) = nn.MaxPool2d(2,2)(a) in ONE pass over y: an encoder block's
  * output feeds the next level through the pool and the decoder through the skip (src/model.py:268-271). */
+/* argidx (optional, NULL to skip) [N][H/2][W/2][roundup(C,8)/8] uint16: per pooled window and 8-channel vector, 2 bits per
+ * channel = position 2*dy + dx of the window's first maximum (ATen's scan order, strict '>'): the pool's backward routing,
+ * consumed by mau_pool_bn_bwd_reduce / _apply. */
 int mau_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const float* shift, void* a, int lda,
-                           void* pooled, int ldp, int dtype, int N, int H, int W, int C, mau_stream_t stream);
+                           void* pooled, int ldp, unsigned short* argidx, int dtype, int N, int H, int W, int C,
+                           mau_stream_t stream);
 /* Backward, pass 1: dz = da * [scale*y+shift > 0]; per-block partial sums of dz and dz*xhat
  * (xhat = (y-mean)*invstd) into slab [rows][2][ldslab]; returns rows via *rows_out (host). */
 int mau_bn_relu_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale,
@@ -202,13 +206,15 @@ int mau_bn_bwd_rows(int64_t npix);
 /* ---- BatchNorm2d + ReLU fused with the streaming operator behind it (csrc/bn_fused.hip) ----
  * An encoder block's output feeds nn.MaxPool2d(2,2) AND a skip connection (src/model.py:268-271 / :279-282).  Backward of its
  * second BatchNorm without ever writing the incoming gradient da = dskip + maxpool_backward(dpl): both passes recompute it
- * (the arg-max from a = relu(scale*y + shift) rounded to `dtype`, as mau_bn_relu_apply_pool stored it).  dpl (N,H/2,W/2) or
+ * (the arg-max from `argidx`, written by mau_bn_relu_apply_pool in the forward pass).  dpl (N,H/2,W/2) [with argidx] or
  * dskip (N,H,W) may be NULL, not both.  slab / sums / count as mau_bn_relu_bwd_reduce / _apply; bit-identical to
  * mau_maxpool2x2_bwd_add + mau_bn_relu_bwd_reduce + mau_bn_relu_bwd_apply. */
-int mau_pool_bn_bwd_reduce(const void* y, int ldy, const void* dpl, int lddpl, const void* dskip, int lddskip,
+int mau_pool_bn_bwd_reduce(const void* y, int ldy, const void* dpl, int lddpl, const unsigned short* argidx,
+                           const void* dskip, int lddskip,
                            const float* scale, const float* shift, const float* mean, const float* invstd, float* slab,
                            int ldslab, int dtype, int N, int H, int W, int C, mau_stream_t stream);
-int mau_pool_bn_bwd_apply(const void* y, int ldy, const void* dpl, int lddpl, const void* dskip, int lddskip,
+int mau_pool_bn_bwd_apply(const void* y, int ldy, const void* dpl, int lddpl, const unsigned short* argidx,
+                          const void* dskip, int lddskip,
                           const float* scale, const float* shift, const float* mean, const float* invstd,
                           const double* sums, double count, void* dy, int lddy, int dtype, int N, int H, int W, int C,
                           mau_stream_t stream);

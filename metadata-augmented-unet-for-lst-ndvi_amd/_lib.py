@@ -57,12 +57,12 @@ PROTOTYPES = {
     "mau_bn_stats_finalize_train": (_i, [_p, _i, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p]),
     "mau_bn_coeffs_eval": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p]),
     "mau_bn_relu_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _i64, _i, _p]),
-    "mau_bn_relu_apply_pool": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_bn_relu_apply_pool": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "mau_bn_relu_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i64, _i, _p]),
     "mau_bn_relu_bwd_apply": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _d, _p, _i, _i, _i64, _i, _p]),
     "mau_bn_bwd_rows": (_i, [_i64]),
-    "mau_pool_bn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "mau_pool_bn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _d, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_pool_bn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mau_pool_bn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _d, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_head_bn_max_channels": (_i, []),
     "mau_head_bn_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_head_bn_bwd_reduce": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),

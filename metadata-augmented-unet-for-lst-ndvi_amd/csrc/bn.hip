@@ -346,9 +346,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const bool ok = c + j < C;
-      sc[j] = ok ? scale[c + j] : 0.f;
-      sh[j] = ok ? shift[c + j] : 0.f;
+      sc[j] = coef(scale, c + j, C);
+      sh[j] = coef(shift, c + j, C);
     }
     int64_t pix = p0 + m.ps;
     for (; pix + 3 * m.PS < p1; pix += 4 * m.PS) {          // 4 independent 16-byte loads in flight per lane
@@ -376,10 +375,14 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
 // a = relu(scale*y + shift) AND p = maxpool2x2(a) in one pass over y (an encoder block's output feeds the next level
 // through nn.MaxPool2d(2,2) and the decoder through the skip connection: reference src/model.py:268-271).
 // One thread = one 2x2 window x 8 channels; grid = (x-chunks of the window row, window rows incl. a last odd row, images).
+// argidx (optional) [N][H/2][W/2][C8/8] uint16: for each pooled window and 8-channel vector, 2 bits per channel = position
+// (2*dy + dx) of the window's FIRST maximum (scan order and strict '>' of ATen's max_pool2d) -- what the backward needs to route
+// the pooled gradient, so that it never re-derives it from the activations (csrc/bn_fused.hip).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, T* __restrict__ a, int lda,
-                                                                 T* __restrict__ pl, int ldp, int H, int W, int C, int C8) {
+                                                                 T* __restrict__ pl, int ldp, unsigned short* __restrict__ argidx, int H, int W,
+                                                                 int C, int C8) {
   const int nv = C8 >> 3, Wc = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Wc * nv) return;
@@ -388,9 +391,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __rest
   float sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const bool ok = c + j < C;
-    sc[j] = ok ? scale[c + j] : 0.f;
-    sh[j] = ok ? shift[c + j] : 0.f;
+    sc[j] = coef(scale, c + j, C);
+    sh[j] = coef(shift, c + j, C);
   }
   const int y0 = 2 * yo, x0 = 2 * xo;
   const bool hasx = x0 + 1 < W, hasy = y0 + 1 < H;
@@ -412,10 +414,23 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __rest
   if (yo < Ho && xo < Wo) {
     // the pooled value is the max of the ROUNDED activations (what a separate pool pass would read back)
     F8 m;
+    unsigned bits = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      m.v[j] = fmaxf(fmaxf((float)(T)o[0].v[j], (float)(T)o[1].v[j]), fmaxf((float)(T)o[2].v[j], (float)(T)o[3].v[j]));
+    for (int j = 0; j < 8; ++j) {
+      const float a0 = (float)(T)o[0].v[j], a1 = (float)(T)o[1].v[j], a2 = (float)(T)o[2].v[j], a3 = (float)(T)o[3].v[j];
+      unsigned arg = 0;
+      float mx = a0;
+      arg = a1 > mx ? 1u : arg;
+      mx = fmaxf(mx, a1);
+      arg = a2 > mx ? 2u : arg;
+      mx = fmaxf(mx, a2);
+      arg = a3 > mx ? 3u : arg;
+      mx = fmaxf(mx, a3);
+      m.v[j] = mx;
+      bits |= arg << (2 * j);
+    }
     store8<T>(pl + (((size_t)n * Ho + yo) * Wo + xo) * ldp + c, m);
+    if (argidx != nullptr) argidx[(((size_t)n * Ho + yo) * Wo + xo) * nv + (c >> 3)] = (unsigned short)bits;
   }
 }
 
@@ -438,11 +453,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
   for (int j = 0; j < 8; ++j) {
     s1[j] = s2[j] = 0.f;
     const int cc = c0 + j;
-    const bool ok = cc < C;
-    sc[j] = ok ? scale[cc] : 0.f;
-    sh[j] = ok ? shift[cc] : 0.f;
-    mu[j] = ok ? mean[cc] : 0.f;
-    is[j] = ok ? invstd[cc] : 0.f;
+    sc[j] = coef(scale, cc, C);
+    sh[j] = coef(shift, cc, C);
+    mu[j] = coef(mean, cc, C);
+    is[j] = coef(invstd, cc, C);
   }
   if (c0 < C) {
     int64_t p = p0 + ps;
@@ -508,16 +522,24 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
     const int c = vv * 8;
     // dy = sc*(dz - m1 - xhat*m2), xhat = (y - mu)*is   ==>   dy = sc*dz - k0 - k1*y
     float sc[8], sh[8], k0[8], k1[8];
+    double d1[8], d2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                        // all 48 loads first, no wait between them (mau_common.h: coef)
+      sc[j] = coef(scale, c + j, C);
+      sh[j] = coef(shift, c + j, C);
+      k0[j] = coef(mean, c + j, C);
+      k1[j] = coef(invstd, c + j, C);
+      d1[j] = coef(sums, c + j, C);
+      d2[j] = coef(sums + C, c + j, C);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int cc = c + j;
-      const bool ok = cc < C;
-      sc[j] = ok ? scale[cc] : 0.f;
-      sh[j] = ok ? shift[cc] : 0.f;
-      const float mu = ok ? mean[cc] : 0.f, is = ok ? invstd[cc] : 0.f;
-      const float m1 = ok ? (float)(sums[cc] * inv_count) : 0.f, m2 = ok ? (float)(sums[C + cc] * inv_count) : 0.f;
-      k1[j] = sc[j] * m2 * is;
-      k0[j] = sc[j] * m1 - k1[j] * mu;
+      const float mu = k0[j], is = k1[j];
+      const float m1 = (float)(d1[j] * inv_count), m2 = (float)(d2[j] * inv_count);
+      // (every product rounded on its own, the difference one explicit FMA: the generic and the fused apply kernels must agree
+      //  to the bit -- left to the compiler, "a*b - c*d" contracts differently from kernel to kernel, visible in fp16 outputs)
+      k1[j] = __fmul_rn(__fmul_rn(sc[j], m2), is);
+      k0[j] = fmaf(sc[j], m1, -__fmul_rn(k1[j], mu));
     }
     int64_t pix = p0 + m.ps;
     for (; pix + 3 * m.PS < p1; pix += 4 * m.PS) {          // 8 independent 16-byte loads in flight per lane
@@ -659,14 +681,14 @@ int mau_bn_relu_apply(const void* y, int ldy, const float* scale, const float* s
 }
 
 int mau_bn_relu_apply_pool(const void* y, int ldy, const float* scale, const float* shift, void* a, int lda, void* pooled,
-                           int ldp, int dtype, int N, int H, int W, int C, mau_stream_t stream) {
+                           int ldp, unsigned short* argidx, int dtype, int N, int H, int W, int C, mau_stream_t stream) {
   MAU_REQUIRE(y && a && pooled && scale && shift && N > 0 && H >= 2 && W >= 2 && C > 0, "bn_relu_apply_pool: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && lda % 8 == 0 && ldp % 8 == 0 && ldy >= C8 && lda >= C8 && ldp >= C8, "bn_relu_apply_pool: bad ld");
   MAU_REQUIRE((H + 1) / 2 <= 65535 && N <= 65535, "bn_relu_apply_pool: H/2 and N must fit a grid dimension");
   dim3 grid(ceil_div(((W + 1) / 2) * (C8 / 8), 256), (H + 1) / 2, N);
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(bn_relu_apply_pool_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, scale,
-                                       shift, (T*)a, lda, (T*)pooled, ldp, H, W, C, C8));
+                                       shift, (T*)a, lda, (T*)pooled, ldp, argidx, H, W, C, C8));
   return check_launch("bn_relu_apply_pool_kernel");
 }
 

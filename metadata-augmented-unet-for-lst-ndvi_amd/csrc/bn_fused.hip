@@ -5,8 +5,8 @@
 //     unfused:  maxpool2x2_bwd_add (read a, dpl, dskip; write da) -> bn_relu_bwd_reduce (read da, y) -> bn_relu_bwd_apply (read da, y; write dy)
 //     fused:    pool_bn_bwd_reduce (read y, dpl, dskip)           ->                                   pool_bn_bwd_apply (read y, dpl, dskip; write dy)
 //   da = dskip + scatter(dpl to the first maximum of its 2x2 window of a) is recomputed in registers both times; the
-//   activation a = relu(scale*y + shift) it needs for the arg-max is recomputed from y (rounded to the activation type,
-//   exactly what bn_relu_apply_pool stored).  8.25 S -> 5.5 S bytes for an activation of S bytes, one launch fewer.
+//   arg-max comes from the 2-bit-per-channel index tensor the forward's bn_relu_apply_pool wrote (S / 64 bytes).
+//   8.25 S -> 5.5 S bytes for an activation of S bytes, one launch fewer.
 // Head (final 1x1 conv + tanh) behind the last block's second BatchNorm:
 //     unfused:  bn_relu_apply (y -> a), head_fwd (a -> out);  head_bwd (a, dout -> da, dW, db), bn_relu_bwd_reduce, bn_relu_bwd_apply
 //     fused:    head_bn_fwd (y -> out);  head_bn_bwd_reduce (y, dout -> BatchNorm sums, dW, db), head_bn_bwd_apply (y, dout -> dy)
@@ -30,48 +30,55 @@ struct Coef8 {
   __device__ __forceinline__ void load(const float* scale, const float* shift, const float* mean, const float* invstd, int c0, int C) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const bool ok = c0 + j < C;
-      sc[j] = ok ? scale[c0 + j] : 0.f;
-      sh[j] = ok ? shift[c0 + j] : 0.f;
-      mu[j] = (ok && mean) ? mean[c0 + j] : 0.f;
-      is[j] = (ok && invstd) ? invstd[c0 + j] : 0.f;
+      sc[j] = coef(scale, c0 + j, C);
+      sh[j] = coef(shift, c0 + j, C);
+      mu[j] = mean ? coef(mean, c0 + j, C) : 0.f;
+      is[j] = invstd ? coef(invstd, c0 + j, C) : 0.f;
     }
   }
 };
 
-// gradient arriving at pixel (n, yi, xi) of an activation that feeds MaxPool2d(2,2) and a skip connection:
-//   dskip[pixel] + (dpl[window] if this pixel is the window's first maximum), rounded to T as maxpool_bwd_kernel stores it.
-// yv: this pixel's raw conv output (already loaded).  Window activations are recomputed from y and rounded to T
-// (bn_relu_apply_pool_kernel's stored values), scan order and strict '>' as ATen's max_pool2d.
+// Everything below is STRAIGHT-LINE code: every load is unconditional (indices clamped into the tensor) and conditions only steer
+// selects.  A conditional 16-byte load compiles to an exec-masked block that ends in s_waitcnt vmcnt(0): the first version of
+// these kernels paid one serialized memory round trip per conditional load (2.0-2.7 TB/s of their traffic).
+//
+// Loads of the gradient arriving at pixel (n, yi, xi) of an activation that feeds MaxPool2d(2,2) (POOL) and a skip connection (SKIP).
+// argidx: 2 bits per channel = position of the window's first maximum, written by bn_relu_apply_pool_kernel in the forward pass.
 template <typename T>
-__device__ __forceinline__ F8 pool_grad(const T* __restrict__ y, int ldy, const T* __restrict__ dpl, int lddpl, const T* __restrict__ dskip,
-                                        int lddskip, const Coef8& k, int n, int yi, int xi, int H, int W, int c0) {
+struct PoolLoads {
+  F8 g, sk;
+  unsigned bits;
+  bool inpool;
+  int me;
+};
+template <typename T, bool POOL, bool SKIP>
+__device__ __forceinline__ PoolLoads<T> pool_load(const T* __restrict__ dpl, int lddpl, const unsigned short* __restrict__ argidx, int nv,
+                                                  const T* __restrict__ dskip, int lddskip, int n, int yi, int xi, int H, int W, int c0) {
+  PoolLoads<T> L;
   const int Ho = H >> 1, Wo = W >> 1, yo = yi >> 1, xo = xi >> 1;
-  F8 o = zero8();
-  if (dpl != nullptr && yo < Ho && xo < Wo) {
-    const T* b = y + (((size_t)n * H + 2 * yo) * W + 2 * xo) * ldy + c0;
-    const F8 v00 = load8<T>(b), v01 = load8<T>(b + ldy), v10 = load8<T>(b + (size_t)W * ldy), v11 = load8<T>(b + (size_t)W * ldy + ldy);
-    const F8 g = load8<T>(dpl + (((size_t)n * Ho + yo) * Wo + xo) * lddpl + c0);
-    const int me = (yi & 1) * 2 + (xi & 1);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float a00 = round_to<T>(fmaxf(fmaf(v00.v[j], k.sc[j], k.sh[j]), 0.f)), a01 = round_to<T>(fmaxf(fmaf(v01.v[j], k.sc[j], k.sh[j]), 0.f));
-      const float a10 = round_to<T>(fmaxf(fmaf(v10.v[j], k.sc[j], k.sh[j]), 0.f)), a11 = round_to<T>(fmaxf(fmaf(v11.v[j], k.sc[j], k.sh[j]), 0.f));
-      int arg = 0;
-      float m = a00;
-      if (a01 > m) { m = a01; arg = 1; }
-      if (a10 > m) { m = a10; arg = 2; }
-      if (a11 > m) { m = a11; arg = 3; }
-      o.v[j] = (arg == me) ? g.v[j] : 0.f;
-    }
+  L.inpool = POOL && yo < Ho && xo < Wo;
+  L.me = (yi & 1) * 2 + (xi & 1);
+  L.bits = 0;
+  if constexpr (POOL) {
+    const int yc = yo < Ho ? yo : Ho - 1, xc = xo < Wo ? xo : Wo - 1;       // (H, W >= 2: Ho, Wo >= 1)
+    const size_t win = ((size_t)n * Ho + yc) * Wo + xc;
+    L.g = load8<T>(dpl + win * lddpl + c0);
+    L.bits = argidx[win * nv + (c0 >> 3)];
   }
-  if (dskip != nullptr) {
-    const F8 sk = load8<T>(dskip + (((size_t)n * H + yi) * W + xi) * lddskip + c0);
+  if constexpr (SKIP) L.sk = load8<T>(dskip + (((size_t)n * H + yi) * W + xi) * lddskip + c0);
+  return L;
+}
+// dskip[pixel] + (dpl[window] if this pixel is the window's first maximum), rounded to T as maxpool_bwd_kernel stores it
+template <typename T, bool POOL, bool SKIP>
+__device__ __forceinline__ F8 pool_eval(const PoolLoads<T>& L) {
+  F8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.v[j] += sk.v[j];
+  for (int j = 0; j < 8; ++j) {
+    float r = 0.f;
+    if constexpr (POOL) r = (L.inpool && (int)((L.bits >> (2 * j)) & 3u) == L.me) ? L.g.v[j] : 0.f;
+    if constexpr (SKIP) r += L.sk.v[j];
+    o.v[j] = round_to<T>(r);
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o.v[j] = round_to<T>(o.v[j]);
   return o;
 }
 
@@ -95,8 +102,19 @@ __device__ __forceinline__ void bn_sums_to_slab(float (*red)[32][64 + 1], const 
 }
 
 // ---- pool: backward pass 1 (partial sums of dz and dz * xhat) ----
-template <typename T>
+__device__ __forceinline__ void advance32(int& n, int& yi, int& xi, int H, int W) {
+  xi += 32;
+  while (xi >= W) {
+    xi -= W;
+    if (++yi == H) {
+      yi = 0;
+      ++n;
+    }
+  }
+}
+template <typename T, bool POOL, bool SKIP>
 __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dpl, int lddpl,
+                                                                 const unsigned short* __restrict__ argidx,
                                                                  const T* __restrict__ dskip, int lddskip, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, float* __restrict__ slab, int ldslab,
@@ -111,29 +129,36 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const T* __rest
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  auto accumulate = [&](const F8& v, const F8& g) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float act = fmaf(v.v[j], k.sc[j], k.sh[j]);
+      const float dz = act > 0.f ? g.v[j] : 0.f;
+      s1[j] += dz;
+      s2[j] = fmaf(dz, (v.v[j] - k.mu[j]) * k.is[j], s2[j]);
+    }
+  };
   if (c0 < C) {
     int64_t p = p0 + ps;
-    const int HW = H * W;
+    const int HW = H * W, nv = (C + 7) >> 3;
     int n = (int)(p / HW), r = (int)(p - (int64_t)n * HW);
     int yi = r / W, xi = r - yi * W;
+    for (; p + 32 < p1; p += 64) {                       // two pixels per iteration: their loads are issued together
+      int n2 = n, yi2 = yi, xi2 = xi;
+      advance32(n2, yi2, xi2, H, W);
+      const F8 va = load8<T>(y + p * ldy + c0), vb = load8<T>(y + (p + 32) * ldy + c0);
+      const PoolLoads<T> La = pool_load<T, POOL, SKIP>(dpl, lddpl, argidx, nv, dskip, lddskip, n, yi, xi, H, W, c0);
+      const PoolLoads<T> Lb = pool_load<T, POOL, SKIP>(dpl, lddpl, argidx, nv, dskip, lddskip, n2, yi2, xi2, H, W, c0);
+      accumulate(va, pool_eval<T, POOL, SKIP>(La));
+      accumulate(vb, pool_eval<T, POOL, SKIP>(Lb));
+      n = n2, yi = yi2, xi = xi2;
+      advance32(n, yi, xi, H, W);
+    }
     for (; p < p1; p += 32) {
       const F8 v = load8<T>(y + p * ldy + c0);
-      const F8 g = pool_grad<T>(y, ldy, dpl, lddpl, dskip, lddskip, k, n, yi, xi, H, W, c0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float act = fmaf(v.v[j], k.sc[j], k.sh[j]);
-        const float dz = act > 0.f ? g.v[j] : 0.f;
-        s1[j] += dz;
-        s2[j] = fmaf(dz, (v.v[j] - k.mu[j]) * k.is[j], s2[j]);
-      }
-      xi += 32;
-      while (xi >= W) {
-        xi -= W;
-        if (++yi == H) {
-          yi = 0;
-          ++n;
-        }
-      }
+      const PoolLoads<T> L = pool_load<T, POOL, SKIP>(dpl, lddpl, argidx, nv, dskip, lddskip, n, yi, xi, H, W, c0);
+      accumulate(v, pool_eval<T, POOL, SKIP>(L));
+      advance32(n, yi, xi, H, W);
     }
   }
   bn_sums_to_slab(red, s1, s2, cv, ps, slab, ldslab);
@@ -144,16 +169,24 @@ struct Apply8 {
   float sc[8], sh[8], k0[8], k1[8];
   __device__ __forceinline__ void load(const float* scale, const float* shift, const float* mean, const float* invstd, const double* sums,
                                        double inv_count, int c0, int C) {
+    double d1[8], d2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                        // all 48 loads first, no wait between them
+      sc[j] = coef(scale, c0 + j, C);
+      sh[j] = coef(shift, c0 + j, C);
+      k0[j] = coef(mean, c0 + j, C);
+      k1[j] = coef(invstd, c0 + j, C);
+      d1[j] = coef(sums, c0 + j, C);
+      d2[j] = coef(sums + C, c0 + j, C);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int cc = c0 + j;
-      const bool ok = cc < C;
-      sc[j] = ok ? scale[cc] : 0.f;
-      sh[j] = ok ? shift[cc] : 0.f;
-      const float mu = ok ? mean[cc] : 0.f, is = ok ? invstd[cc] : 0.f;
-      const float m1 = ok ? (float)(sums[cc] * inv_count) : 0.f, m2 = ok ? (float)(sums[C + cc] * inv_count) : 0.f;
-      k1[j] = sc[j] * m2 * is;
-      k0[j] = sc[j] * m1 - k1[j] * mu;
+      const float mu = k0[j], is = k1[j];
+      const float m1 = (float)(d1[j] * inv_count), m2 = (float)(d2[j] * inv_count);
+      // (every product rounded on its own, the difference one explicit FMA: the generic and the fused apply kernels must agree
+      //  to the bit -- left to the compiler, "a*b - c*d" contracts differently from kernel to kernel, visible in fp16 outputs)
+      k1[j] = __fmul_rn(__fmul_rn(sc[j], m2), is);
+      k0[j] = fmaf(sc[j], m1, -__fmul_rn(k1[j], mu));
     }
   }
   __device__ __forceinline__ float dy(int j, float yv, float da) const {
@@ -163,135 +196,145 @@ struct Apply8 {
   }
 };
 
-// ---- pool: backward pass 2; one thread = one 2x2 window x 8 channels (the four y vectors serve arg-max and dy alike) ----
-template <typename T>
+// ---- pool: backward pass 2; one thread = a column of RY 2x2 windows x 8 channels (the four y vectors of a window serve arg-max
+// and dy alike; the per-channel coefficients are set up once per thread) ----
+template <typename T, bool POOL, bool SKIP>
 __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ dpl, int lddpl,
+                                                                const unsigned short* __restrict__ argidx,
                                                                 const T* __restrict__ dskip, int lddskip, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const double* __restrict__ sums,
-                                                                double inv_count, T* __restrict__ dyo, int lddy, int H, int W, int C, int C8) {
-  const int nv = C8 >> 3, Wc = (W + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
+                                                                double inv_count, T* __restrict__ dyo, int lddy, int H, int W, int C, int C8,
+                                                                int RY) {
+  const int nv = C8 >> 3, Wc = (W + 1) >> 1, Hc = (H + 1) >> 1, Ho = H >> 1, Wo = W >> 1;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Wc * nv) return;
   const int xo = idx / nv, c = (idx - xo * nv) * 8;
-  const int yo = blockIdx.y, n = blockIdx.z;
+  const int n = blockIdx.z;
   if (inv_count <= 0.0) inv_count = 1.0 / sums[2 * C];
   Apply8 k;
   k.load(scale, shift, mean, invstd, sums, inv_count, c, C);
-  const int y0 = 2 * yo, x0 = 2 * xo;
-  const bool hasx = x0 + 1 < W, hasy = y0 + 1 < H;
-  const size_t row0 = ((size_t)n * H + y0) * W, row1 = row0 + W;
-  F8 v[4];
-  v[0] = load8<T>(y + (row0 + x0) * ldy + c);
-  v[1] = hasx ? load8<T>(y + (row0 + x0 + 1) * ldy + c) : zero8();
-  v[2] = hasy ? load8<T>(y + (row1 + x0) * ldy + c) : zero8();
-  v[3] = (hasx && hasy) ? load8<T>(y + (row1 + x0 + 1) * ldy + c) : zero8();
-  F8 d[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) d[u] = zero8();
-  if (dskip != nullptr) {
-    d[0] = load8<T>(dskip + (row0 + x0) * lddskip + c);
-    if (hasx) d[1] = load8<T>(dskip + (row0 + x0 + 1) * lddskip + c);
-    if (hasy) d[2] = load8<T>(dskip + (row1 + x0) * lddskip + c);
-    if (hasx && hasy) d[3] = load8<T>(dskip + (row1 + x0 + 1) * lddskip + c);
-  }
-  if (dpl != nullptr && yo < Ho && xo < Wo) {             // (inside the pooled range all four pixels exist)
-    const F8 g = load8<T>(dpl + (((size_t)n * Ho + yo) * Wo + xo) * lddpl + c);
+  const int x0 = 2 * xo;
+  const bool hasx = x0 + 1 < W;
+  const int x1 = hasx ? x0 + 1 : x0;                     // (clamped: a duplicate load whose result is never stored)
+  const int xpc = xo < Wo ? xo : Wo - 1;
+  for (int yo = blockIdx.y * RY; yo < min(Hc, (int)(blockIdx.y + 1) * RY); ++yo) {
+    const int y0 = 2 * yo;
+    const bool hasy = y0 + 1 < H;
+    const size_t row0 = ((size_t)n * H + y0) * W, row1 = ((size_t)n * H + (hasy ? y0 + 1 : y0)) * W;
+    F8 v[4], d[4], g;
+    v[0] = load8<T>(y + (row0 + x0) * ldy + c);
+    v[1] = load8<T>(y + (row0 + x1) * ldy + c);
+    v[2] = load8<T>(y + (row1 + x0) * ldy + c);
+    v[3] = load8<T>(y + (row1 + x1) * ldy + c);
+    if constexpr (SKIP) {
+      d[0] = load8<T>(dskip + (row0 + x0) * lddskip + c);
+      d[1] = load8<T>(dskip + (row0 + x1) * lddskip + c);
+      d[2] = load8<T>(dskip + (row1 + x0) * lddskip + c);
+      d[3] = load8<T>(dskip + (row1 + x1) * lddskip + c);
+    }
+    const bool inpool = POOL && yo < Ho && xo < Wo;      // (inside the pooled range all four pixels exist)
+    unsigned bits = 0;
+    if constexpr (POOL) {
+      const size_t win = ((size_t)n * Ho + (yo < Ho ? yo : Ho - 1)) * Wo + xpc;
+      g = load8<T>(dpl + win * lddpl + c);
+      bits = argidx[win * nv + (c >> 3)];
+    }
+    F8 o[4];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float a[4];
+      const int arg = inpool ? (int)((bits >> (2 * j)) & 3u) : -1;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = round_to<T>(fmaxf(fmaf(v[u].v[j], k.sc[j], k.sh[j]), 0.f));
-      int arg = 0;
-      float m = a[0];
-      if (a[1] > m) { m = a[1]; arg = 1; }
-      if (a[2] > m) { m = a[2]; arg = 2; }
-      if (a[3] > m) { m = a[3]; arg = 3; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) d[u].v[j] = (arg == u ? g.v[j] : 0.f) + d[u].v[j];
+      for (int u = 0; u < 4; ++u) {
+        float r = 0.f;
+        if constexpr (POOL) r = arg == u ? g.v[j] : 0.f;
+        if constexpr (SKIP) r += d[u].v[j];
+        o[u].v[j] = k.dy(j, v[u].v[j], round_to<T>(r));
+      }
     }
+    store8<T>(dyo + (row0 + x0) * lddy + c, o[0]);
+    if (hasx) store8<T>(dyo + (row0 + x0 + 1) * lddy + c, o[1]);
+    if (hasy) store8<T>(dyo + (row1 + x0) * lddy + c, o[2]);
+    if (hasx && hasy) store8<T>(dyo + (row1 + x0 + 1) * lddy + c, o[3]);
   }
-  F8 o[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[u].v[j] = k.dy(j, v[u].v[j], round_to<T>(d[u].v[j]));
-  store8<T>(dyo + (row0 + x0) * lddy + c, o[0]);
-  if (hasx) store8<T>(dyo + (row0 + x0 + 1) * lddy + c, o[1]);
-  if (hasy) store8<T>(dyo + (row1 + x0) * lddy + c, o[2]);
-  if (hasx && hasy) store8<T>(dyo + (row1 + x0 + 1) * lddy + c, o[3]);
 }
 
 // ---- head: forward with BatchNorm + ReLU applied while the activation is loaded (head_fwd_kernel's mapping and arithmetic) ----
-template <typename T>
+template <typename T, int MC>
 __global__ __launch_bounds__(256) void head_bn_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ w,
                                                           const float* __restrict__ b, float* __restrict__ out, int tanh0, int HW, int C,
                                                           int Co, int64_t npix) {
   const int sub = threadIdx.x & 7;
-  float wr[HEAD_MAX_CO][8];
+  float wr[MC][8];
 #pragma unroll
-  for (int o = 0; o < HEAD_MAX_CO; ++o)
+  for (int o = 0; o < MC; ++o)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wr[o][j] = (o < Co && sub * 8 + j < C) ? w[o * C + sub * 8 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) wr[o][j] = o < Co ? coef(w + o * C, sub * 8 + j, C) : 0.f;
   Coef8 k;
   k.load(scale, shift, nullptr, nullptr, sub * 8, C);
-  const int64_t stride = (int64_t)gridDim.x * 32;
-  for (int64_t pix0 = (int64_t)blockIdx.x * 32; pix0 < npix; pix0 += stride) {      // block-uniform trip count
-    const int64_t pix = pix0 + (threadIdx.x >> 3);
-    const bool live = pix < npix;
-    float acc[HEAD_MAX_CO];
+  // four pixels per thread and iteration (their loads are issued together); block-uniform trip count
+  const int64_t stride = (int64_t)gridDim.x * 128;
+  for (int64_t pix0 = (int64_t)blockIdx.x * 128; pix0 < npix; pix0 += stride) {
+    F8 x[4];
 #pragma unroll
-    for (int o = 0; o < HEAD_MAX_CO; ++o) acc[o] = 0.f;
-    if (live && sub * 8 < C) {
-      const F8 x = load8<T>(y + pix * ldy + sub * 8);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t pix = pix0 + 32 * u + (threadIdx.x >> 3);
+      const int64_t pc = pix < npix ? pix : npix - 1;                      // (clamped: unconditional load)
+      x[u] = load8<T>(y + pc * ldy + (sub * 8 < C ? sub * 8 : 0));
+    }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float a = round_to<T>(fmaxf(fmaf(x.v[j], k.sc[j], k.sh[j]), 0.f));
+    for (int u = 0; u < 4; ++u) {
+      const int64_t pix = pix0 + 32 * u + (threadIdx.x >> 3);
+      const bool live = pix < npix;
+      float acc[MC];
 #pragma unroll
-        for (int o = 0; o < HEAD_MAX_CO; ++o) acc[o] = fmaf(a, wr[o][j], acc[o]);
+      for (int o = 0; o < MC; ++o) acc[o] = 0.f;
+      if (sub * 8 < C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a = round_to<T>(fmaxf(fmaf(x[u].v[j], k.sc[j], k.sh[j]), 0.f));
+#pragma unroll
+          for (int o = 0; o < MC; ++o) acc[o] = fmaf(a, wr[o][j], acc[o]);
+        }
       }
-    }
 #pragma unroll
-    for (int o = 0; o < HEAD_MAX_CO; ++o) {
-      acc[o] += __shfl_xor(acc[o], 1);
-      acc[o] += __shfl_xor(acc[o], 2);
-      acc[o] += __shfl_xor(acc[o], 4);
-    }
-    if (live && sub < Co) {
-      float r = 0.f;
+      for (int o = 0; o < MC; ++o) {
+        acc[o] += __shfl_xor(acc[o], 1);
+        acc[o] += __shfl_xor(acc[o], 2);
+        acc[o] += __shfl_xor(acc[o], 4);
+      }
+      if (live && sub < Co) {
+        float r = 0.f;
 #pragma unroll
-      for (int o = 0; o < HEAD_MAX_CO; ++o)
-        if (o == sub) r = acc[o];
-      r += b[sub];
-      if (tanh0 && sub == 0) r = tanhf(r);
-      const int64_t n = pix / HW, q = pix - n * HW;
-      out[((size_t)n * Co + sub) * HW + q] = r;
+        for (int o = 0; o < MC; ++o)
+          if (o == sub) r = acc[o];
+        r += b[sub];
+        if (tanh0 && sub == 0) r = tanhf(r);
+        const int64_t n = pix / HW, q = pix - n * HW;
+        out[((size_t)n * Co + sub) * HW + q] = r;
+      }
     }
   }
 }
 
-// dz of the head at pixel (n, q): dout * (1 - out^2) on the tanh channel
+// dz of the head at pixel (n, q): dout * (1 - out^2) on the tanh channel (unconditional loads, clamped channel index)
+template <int MC>
 __device__ __forceinline__ void head_dz(const float* __restrict__ out, const float* __restrict__ dout, int tanh0, int Co, int HW, int64_t n,
                                         int q, float* dz) {
+  const size_t base = (size_t)n * Co * HW + q;
+  const float t = out[base];
+  const float f0 = tanh0 ? fmaf(-t, t, 1.f) : 1.f;
 #pragma unroll
-  for (int o = 0; o < HEAD_MAX_CO; ++o) {
-    dz[o] = 0.f;
-    if (o < Co) {
-      const size_t oi = ((size_t)n * Co + o) * HW + q;
-      float g = dout[oi];
-      if (tanh0 && o == 0) {
-        const float t = out[oi];
-        g *= (1.f - t * t);
-      }
-      dz[o] = g;
-    }
+  for (int o = 0; o < MC; ++o) {
+    const float g = dout[base + (size_t)(o < Co ? o : Co - 1) * HW];
+    dz[o] = o < Co ? (o == 0 ? g * f0 : g) : 0.f;
   }
 }
 
 // ---- head: backward pass 1.  One workgroup = BWD_PIX_PER_BLOCK pixels x all C <= 64 channels: BatchNorm partial sums (slab row
 // as bn_relu_bwd_reduce_kernel) and the head's dW / db partials (slab row as head_bwd_kernel) in one pass over y ----
-template <typename T>
+template <typename T, int MC>
 __global__ __launch_bounds__(256) void head_bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ w,
@@ -308,52 +351,74 @@ __global__ __launch_bounds__(256) void head_bn_bwd_reduce_kernel(const T* __rest
   float* row = head_slab + (size_t)blockIdx.x * rowlen;
   Coef8 k;
   k.load(scale, shift, mean, invstd, c0, C);
-  float s1[8], s2[8], dwp[HEAD_MAX_CO][8], dbp[HEAD_MAX_CO], wr[HEAD_MAX_CO][8];
+  float s1[8], s2[8], dwp[MC][8], dbp[MC], wr[MC][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
-  for (int o = 0; o < HEAD_MAX_CO; ++o) {
+  for (int o = 0; o < MC; ++o) {
     dbp[o] = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       dwp[o][j] = 0.f;
-      wr[o][j] = (o < Co && c0 + j < C) ? w[o * C + c0 + j] : 0.f;
+      wr[o][j] = o < Co ? coef(w + o * C, c0 + j, C) : 0.f;
     }
   }
+  auto one = [&](const F8& v, const float* dz) {
+#pragma unroll
+    for (int o = 0; o < MC; ++o) dbp[o] += dz[o];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float act = fmaf(v.v[j], k.sc[j], k.sh[j]);
+      const float a = round_to<T>(fmaxf(act, 0.f));                 // the activation bn_relu_apply stored
+      float s = 0.f;
+#pragma unroll
+      for (int o = 0; o < MC; ++o)
+        if (o < Co) {
+          s = fmaf(dz[o], wr[o][j], s);
+          dwp[o][j] = fmaf(dz[o], a, dwp[o][j]);
+        }
+      const float da = round_to<T>(s);                              // the gradient head_bwd stored
+      const float dzb = act > 0.f ? da : 0.f;
+      s1[j] += dzb;
+      s2[j] = fmaf(dzb, (v.v[j] - k.mu[j]) * k.is[j], s2[j]);
+    }
+  };
+  auto wrap = [&](int64_t& n, int& q) {
+    while (q >= HW) {
+      q -= HW;
+      ++n;
+    }
+  };
   if (c0 < C8) {
     int64_t n = (p0 + ps) / HW;
     int q = (int)((p0 + ps) - n * HW);
-    for (int64_t p = p0 + ps; p < p1; p += 32, q += 32) {
-      while (q >= HW) {
-        q -= HW;
-        ++n;
-      }
-      float dz[HEAD_MAX_CO];
-      head_dz(out, dout, tanh0, Co, HW, n, q, dz);
-#pragma unroll
-      for (int o = 0; o < HEAD_MAX_CO; ++o) dbp[o] += dz[o];
+    int64_t p = p0 + ps;
+    for (; p + 32 < p1; p += 64) {                       // two pixels per iteration: their loads are issued together (four: slower,
+      int64_t n2 = n;                                    //  the 2 x (dW, db) accumulators leave no room for four vectors in flight)
+      int q2 = q + 32;
+      wrap(n2, q2);
+      float dza[MC], dzb2[MC];
+      const F8 va = load8<T>(y + p * ldy + c0), vb = load8<T>(y + (p + 32) * ldy + c0);
+      head_dz<MC>(out, dout, tanh0, Co, HW, n, q, dza);
+      head_dz<MC>(out, dout, tanh0, Co, HW, n2, q2, dzb2);
+      one(va, dza);
+      one(vb, dzb2);
+      n = n2;
+      q = q2 + 32;
+      wrap(n, q);
+    }
+    for (; p < p1; p += 32) {
+      float dz[MC];
       const F8 v = load8<T>(y + p * ldy + c0);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float act = fmaf(v.v[j], k.sc[j], k.sh[j]);
-        const float a = round_to<T>(fmaxf(act, 0.f));                 // the activation bn_relu_apply stored
-        float s = 0.f;
-#pragma unroll
-        for (int o = 0; o < HEAD_MAX_CO; ++o)
-          if (o < Co) {
-            s = fmaf(dz[o], wr[o][j], s);
-            dwp[o][j] = fmaf(dz[o], a, dwp[o][j]);
-          }
-        const float da = round_to<T>(s);                              // the gradient head_bwd stored
-        const float dzb = act > 0.f ? da : 0.f;
-        s1[j] += dzb;
-        s2[j] = fmaf(dzb, (v.v[j] - k.mu[j]) * k.is[j], s2[j]);
-      }
+      head_dz<MC>(out, dout, tanh0, Co, HW, n, q, dz);
+      one(v, dz);
+      q += 32;
+      wrap(n, q);
     }
   }
   // head partials (head_bwd_kernel's LDS join; one 64-channel group)
 #pragma unroll
-  for (int o = 0; o < HEAD_MAX_CO; ++o)
+  for (int o = 0; o < MC; ++o)
     if (o < Co) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) hred[(ps * HEAD_MAX_CO + o) * 65 + cv * 8 + j] = dwp[o][j];
@@ -368,7 +433,7 @@ __global__ __launch_bounds__(256) void head_bn_bwd_reduce_kernel(const T* __rest
   __syncthreads();
   if (cv == 0) {
 #pragma unroll
-    for (int o = 0; o < HEAD_MAX_CO; ++o)
+    for (int o = 0; o < MC; ++o)
       if (o < Co) hred[ps * HEAD_MAX_CO + o] = dbp[o];
   }
   __syncthreads();
@@ -382,7 +447,7 @@ __global__ __launch_bounds__(256) void head_bn_bwd_reduce_kernel(const T* __rest
 }
 
 // ---- head: backward pass 2: dy of the conv in front of the BatchNorm, da recomputed from dout ----
-template <typename T>
+template <typename T, int MC>
 __global__ __launch_bounds__(256) void head_bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const double* __restrict__ sums,
@@ -395,33 +460,61 @@ __global__ __launch_bounds__(256) void head_bn_bwd_apply_kernel(const T* __restr
   if (inv_count <= 0.0) inv_count = 1.0 / sums[2 * C];
   Apply8 k;
   k.load(scale, shift, mean, invstd, sums, inv_count, c0, C);
-  float wr[HEAD_MAX_CO][8];
+  float wr[MC][8];
 #pragma unroll
-  for (int o = 0; o < HEAD_MAX_CO; ++o)
+  for (int o = 0; o < MC; ++o)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wr[o][j] = (o < Co && c0 + j < C) ? w[o * C + c0 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) wr[o][j] = o < Co ? coef(w + o * C, c0 + j, C) : 0.f;
   const int64_t p0 = (int64_t)blockIdx.x * pixb;
   const int64_t p1 = p0 + pixb < npix ? p0 + pixb : npix;
   int64_t n = (p0 + ps) / HW;
   int q = (int)((p0 + ps) - n * HW);
-  for (int64_t p = p0 + ps; p < p1; p += 32, q += 32) {
-    while (q >= HW) {
-      q -= HW;
-      ++n;
+  auto wrap = [&](int64_t& nn, int& qq) {
+    while (qq >= HW) {
+      qq -= HW;
+      ++nn;
     }
-    float dz[HEAD_MAX_CO];
-    head_dz(out, dout, tanh0, Co, HW, n, q, dz);
-    const F8 v = load8<T>(y + p * ldy + c0);
+  };
+  auto one = [&](int64_t p, const F8& v, const float* dz) {
     F8 o8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float s = 0.f;
 #pragma unroll
-      for (int o = 0; o < HEAD_MAX_CO; ++o)
+      for (int o = 0; o < MC; ++o)
         if (o < Co) s = fmaf(dz[o], wr[o][j], s);
       o8.v[j] = k.dy(j, v.v[j], round_to<T>(s));
     }
     store8<T>(dyo + p * lddy + c0, o8);
+  };
+  int64_t p = p0 + ps;
+  for (; p + 96 < p1; p += 128) {                        // four pixels per iteration: their loads are issued together
+    int64_t nn[4];
+    int qq[4];
+    F8 v[4];
+    float dz[4][MC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      nn[u] = n;
+      qq[u] = q;
+      q += 32;
+      wrap(n, q);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = load8<T>(y + (p + 32 * u) * ldy + c0);
+      head_dz<MC>(out, dout, tanh0, Co, HW, nn[u], qq[u], dz[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(p + 32 * u, v[u], dz[u]);
+  }
+  for (; p < p1; p += 32) {
+    float dz[MC];
+    const F8 v = load8<T>(y + p * ldy + c0);
+    head_dz<MC>(out, dout, tanh0, Co, HW, n, q, dz);
+    one(p, v, dz);
+    q += 32;
+    wrap(n, q);
   }
 }
 
@@ -431,33 +524,47 @@ using namespace mau;
 
 extern "C" {
 
-int mau_pool_bn_bwd_reduce(const void* y, int ldy, const void* dpl, int lddpl, const void* dskip, int lddskip, const float* scale,
+int mau_pool_bn_bwd_reduce(const void* y, int ldy, const void* dpl, int lddpl, const unsigned short* argidx, const void* dskip, int lddskip, const float* scale,
                            const float* shift, const float* mean, const float* invstd, float* slab, int ldslab, int dtype, int N, int H,
                            int W, int C, mau_stream_t stream) {
-  MAU_REQUIRE(y && (dpl || dskip) && scale && shift && mean && invstd && slab && N > 0 && H >= 2 && W >= 2 && C > 0, "pool_bn_bwd_reduce: bad arguments");
+  MAU_REQUIRE(y && (dpl || dskip) && (!dpl || argidx) && scale && shift && mean && invstd && slab && N > 0 && H >= 2 && W >= 2 && C > 0, "pool_bn_bwd_reduce: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && ldy >= C8 && (!dpl || (lddpl % 8 == 0 && lddpl >= C8)) && (!dskip || (lddskip % 8 == 0 && lddskip >= C8)) && ldslab >= C,
               "pool_bn_bwd_reduce: bad ld");
   const int64_t npix = (int64_t)N * H * W;
   dim3 grid(ceil_div(npix, BWD_PIX_PER_BLOCK), ceil_div(C, 64));
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(pool_bn_bwd_reduce_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, (const T*)dpl,
-                                       lddpl, (const T*)dskip, lddskip, scale, shift, mean, invstd, slab, ldslab, H, W, npix, C));
+#define MAU_POOL_REDUCE(P, S)                                                                                                                  \
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((pool_bn_bwd_reduce_kernel<T, P, S>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, (const T*)dpl, \
+                                       lddpl, argidx, (const T*)dskip, lddskip, scale, shift, mean, invstd, slab, ldslab, H, W, npix, C))
+  if (dpl && dskip) MAU_POOL_REDUCE(true, true);
+  else if (dpl) MAU_POOL_REDUCE(true, false);
+  else MAU_POOL_REDUCE(false, true);
+#undef MAU_POOL_REDUCE
   return check_launch("pool_bn_bwd_reduce_kernel");
 }
 
-int mau_pool_bn_bwd_apply(const void* y, int ldy, const void* dpl, int lddpl, const void* dskip, int lddskip, const float* scale,
+int mau_pool_bn_bwd_apply(const void* y, int ldy, const void* dpl, int lddpl, const unsigned short* argidx, const void* dskip, int lddskip, const float* scale,
                           const float* shift, const float* mean, const float* invstd, const double* sums, double count, void* dy, int lddy,
                           int dtype, int N, int H, int W, int C, mau_stream_t stream) {
-  MAU_REQUIRE(y && (dpl || dskip) && dy && sums && scale && shift && mean && invstd && N > 0 && H >= 2 && W >= 2 && C > 0 && count >= 0,
+  MAU_REQUIRE(y && (dpl || dskip) && (!dpl || argidx) && dy && sums && scale && shift && mean && invstd && N > 0 && H >= 2 && W >= 2 && C > 0 && count >= 0,
               "pool_bn_bwd_apply: bad arguments");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && ldy >= C8 && lddy % 8 == 0 && lddy >= C8 && (!dpl || (lddpl % 8 == 0 && lddpl >= C8)) &&
                   (!dskip || (lddskip % 8 == 0 && lddskip >= C8)), "pool_bn_bwd_apply: bad ld");
   MAU_REQUIRE((H + 1) / 2 <= 65535 && N <= 65535, "pool_bn_bwd_apply: H/2 and N must fit a grid dimension");
-  dim3 grid(ceil_div(((W + 1) / 2) * (C8 / 8), 256), (H + 1) / 2, N);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(pool_bn_bwd_apply_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, (const T*)dpl, lddpl,
-                                       (const T*)dskip, lddskip, scale, shift, mean, invstd, sums, count > 0 ? 1.0 / count : 0.0, (T*)dy, lddy,
-                                       H, W, C, C8));
+  // RY window rows per thread (the coefficient set-up -- 48 loads, fp64 means -- is paid once per thread), as long as >= ~2048 workgroups remain
+  const int xb = ceil_div(((W + 1) / 2) * (C8 / 8), 256), Hc = (H + 1) / 2;
+  int RY = 8;
+  while (RY > 1 && (int64_t)xb * ceil_div(Hc, RY) * N < 1024) RY >>= 1;
+  dim3 grid(xb, ceil_div(Hc, RY), N);
+#define MAU_POOL_APPLY(P, S)                                                                                                                   \
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((pool_bn_bwd_apply_kernel<T, P, S>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, (const T*)dpl, lddpl, \
+                                       argidx, (const T*)dskip, lddskip, scale, shift, mean, invstd, sums, count > 0 ? 1.0 / count : 0.0, (T*)dy, lddy, \
+                                       H, W, C, C8, RY))
+  if (dpl && dskip) MAU_POOL_APPLY(true, true);
+  else if (dpl) MAU_POOL_APPLY(true, false);
+  else MAU_POOL_APPLY(false, true);
+#undef MAU_POOL_APPLY
   return check_launch("pool_bn_bwd_apply_kernel");
 }
 
@@ -470,9 +577,14 @@ int mau_head_bn_fwd(const void* y, int ldy, const float* scale, const float* shi
               mau_head_bn_max_channels());
   MAU_REQUIRE(ldy % 8 == 0 && ldy >= round_up(C, 8), "head_bn_fwd: bad ld");
   const int64_t npix = (int64_t)N * HW;
-  const int grid = stream_grid(npix * 8, 256);
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(head_bn_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, scale, shift, w, b,
-                                       out, tanh0, HW, C, Co, npix));
+  const int grid = stream_grid(npix * 2, 256);
+  if (Co <= 2) {      // (the reference's head has two outputs: half the weight / accumulator registers of the general form)
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_fwd_kernel<T, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, scale, shift, w, b,
+                                         out, tanh0, HW, C, Co, npix));
+  } else {
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_fwd_kernel<T, HEAD_MAX_CO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, scale, shift, w, b,
+                                         out, tanh0, HW, C, Co, npix));
+  }
   return check_launch("head_bn_fwd_kernel");
 }
 
@@ -486,9 +598,15 @@ int mau_head_bn_bwd_reduce(const void* y, int ldy, const float* scale, const flo
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && ldy >= C8 && ldslab >= C, "head_bn_bwd_reduce: bad ld");
   const int64_t npix = (int64_t)N * HW;
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(head_bn_bwd_reduce_kernel<T>, dim3(ceil_div(npix, BWD_PIX_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
-                                       (const T*)y, ldy, scale, shift, mean, invstd, w, out, dout, bn_slab, ldslab, head_slab, tanh0, HW, C, C8,
-                                       Co, npix));
+  if (Co <= 2) {
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_reduce_kernel<T, 2>), dim3(ceil_div(npix, BWD_PIX_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)y, ldy, scale, shift, mean, invstd, w, out, dout, bn_slab, ldslab, head_slab, tanh0, HW, C, C8,
+                                         Co, npix));
+  } else {
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_reduce_kernel<T, HEAD_MAX_CO>), dim3(ceil_div(npix, BWD_PIX_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)y, ldy, scale, shift, mean, invstd, w, out, dout, bn_slab, ldslab, head_slab, tanh0, HW, C, C8,
+                                         Co, npix));
+  }
   return check_launch("head_bn_bwd_reduce_kernel");
 }
 
@@ -502,10 +620,16 @@ int mau_head_bn_bwd_apply(const void* y, int ldy, const float* scale, const floa
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && ldy >= C8 && lddy % 8 == 0 && lddy >= C8, "head_bn_bwd_apply: bad ld");
   const int64_t npix = (int64_t)N * HW;
-  const int pixb = 256;                                      // 8 pixels per thread; >= 2048 workgroups at 2M pixels
-  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(head_bn_bwd_apply_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy,
-                                       scale, shift, mean, invstd, sums, count > 0 ? 1.0 / count : 0.0, w, out, dout, (T*)dy, lddy, tanh0, HW, C,
-                                       Co, npix, pixb));
+  const int pixb = npix >= ((int64_t)1 << 20) ? 1024 : 256;   // 32 (8) pixels per thread: the coefficient set-up is paid once per thread
+  if (Co <= 2) {
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_apply_kernel<T, 2>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy,
+                                         scale, shift, mean, invstd, sums, count > 0 ? 1.0 / count : 0.0, w, out, dout, (T*)dy, lddy, tanh0, HW, C,
+                                         Co, npix, pixb));
+  } else {
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_apply_kernel<T, HEAD_MAX_CO>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy,
+                                         scale, shift, mean, invstd, sums, count > 0 ? 1.0 / count : 0.0, w, out, dout, (T*)dy, lddy, tanh0, HW, C,
+                                         Co, npix, pixb));
+  }
   return check_launch("head_bn_bwd_apply_kernel");
 }
 

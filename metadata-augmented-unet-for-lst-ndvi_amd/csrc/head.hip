@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ a, 
             float g = dout[oi];
             if (tanh0 && o == 0) {
               const float t = out[oi];
-              g *= (1.f - t * t);
+              g *= fmaf(-t, t, 1.f);              // (explicit: bn_fused.hip's head_dz must round alike)
             }
             dz[o] = g;
             dbp[o] += g;

@@ -162,6 +162,18 @@ __device__ __forceinline__ void store8_nt<f16>(f16* p, const F8& r) {
   __builtin_nontemporal_store(a, reinterpret_cast<f16x8*>(p));
 }
 
+// Per-channel coefficient of channel c (0 beyond C).  The load is UNCONDITIONAL (clamped index) and the zero a select: written as
+// `c < C ? p[c] : 0.f` every element became an exec-masked branch around its own load (and, for the fp64 sums, a full
+// s_waitcnt vmcnt(0) inside it): 16-48 serialized memory round trips at the head of every thread of the streaming kernels.
+__device__ __forceinline__ float coef(const float* __restrict__ p, int c, int C) {
+  const float v = p[c < C ? c : C - 1];
+  return c < C ? v : 0.f;
+}
+__device__ __forceinline__ double coef(const double* __restrict__ p, int c, int C) {
+  const double v = p[c < C ? c : C - 1];
+  return c < C ? v : 0.0;
+}
+
 __device__ __forceinline__ F8 zero8() {
   F8 r;
 #pragma unroll

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void resize_fwd_cell_kernel(const T* __restric
   if constexpr (BN) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float sc = c + e < C ? scale[c + e] : 0.f, sh = c + e < C ? shift[c + e] : 0.f;
+      const float sc = coef(scale, c + e, C), sh = coef(shift, c + e, C);
       v00.v[e] = (float)(T)fmaxf(fmaf(v00.v[e], sc, sh), 0.f);
       v01.v[e] = (float)(T)fmaxf(fmaf(v01.v[e], sc, sh), 0.f);
       v10.v[e] = (float)(T)fmaxf(fmaf(v10.v[e], sc, sh), 0.f);
@@ -255,6 +255,93 @@ __global__ __launch_bounds__(256) void resize_fwd_cell_kernel(const T* __restric
         o.v[e] = lerp4(ly0, ly1, lx0, lx1, v00.v[e], v01.v[e], v10.v[e], v11.v[e]);
       store8<T>(dst + (((size_t)n * H + j) * W + k) * lddst + choff + c, o);
     }
+  }
+}
+
+// Upsamplings by at most ~2 (every decoder resize of the models): a COLUMN of RY source cells per thread.  The (at most 3)
+// destination columns of the thread's source column are set up once, a cell's bottom corners become the next cell's top
+// corners (two loads per cell instead of four), and the next row's loads are in flight while the current cell's destination
+// pixels are written: 1.0-1.4x the one-cell-per-thread form.  BN: the source is the RAW conv output of a block whose
+// BatchNorm + ReLU has this upsample as its only consumer -- relu(scale*y + shift), rounded to T as bn_relu_apply stores it, is
+// formed on the corners in registers.  Coordinates and interpolation arithmetic are resize_fwd_kernel's (bit-identical).
+template <typename T, bool BN>
+__global__ __launch_bounds__(256) void resize_rows_kernel(const T* __restrict__ src, int ldsrc, int h, int w, T* __restrict__ dst,
+                                                             int lddst, int choff, int H, int W, int C8, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int C, int RY) {
+  const int nv = C8 >> 3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= w * nv) return;
+  const int xs = idx / nv, c = (idx - xs * nv) * 8;
+  const int n = blockIdx.z, ys0 = blockIdx.y * RY, ys_end = min(h, ys0 + RY);
+  float sc[8], sh[8];
+  if constexpr (BN) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = coef(scale, c + e, C);
+      sh[e] = coef(shift, c + e, C);
+    }
+  }
+  auto bnr = [&](const F8& v) {
+    if constexpr (!BN) return v;
+    F8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.v[e] = (float)(T)fmaxf(fmaf(v.v[e], sc[e], sh[e]), 0.f);
+    return o;
+  };
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  const int xs1 = xs + (xs < w - 1 ? 1 : 0);
+  // destination columns whose left source column is xs (at most 3 at scales >= ~1/2: the launcher guarantees it)
+  int kcol[3] = {0, 0, 0}, ncol = 0;
+  float clx0[3] = {0.f, 0.f, 0.f}, clx1[3] = {0.f, 0.f, 0.f};
+  {
+    int ka = 0, kb = W - 1;
+    if (sx > 0.f) {
+      ka = max(0, (int)floorf((float)xs / sx) - 1);
+      kb = min(W - 1, (int)ceilf(((float)xs + 1.f) / sx) + 1);
+    }
+    for (int k = ka; k <= kb; ++k) {
+      int x0, x1;
+      float lx0, lx1;
+      ac_src(sx, k, w, x0, x1, lx0, lx1);
+      if (x0 == xs && ncol < 3) {
+        kcol[ncol] = k;
+        clx0[ncol] = lx0;
+        clx1[ncol] = lx1;
+        ++ncol;
+      }
+    }
+  }
+  const T* b = src + (size_t)n * h * w * ldsrc + c;
+  F8 t0 = bnr(load8<T>(b + ((size_t)ys0 * w + xs) * ldsrc)), t1 = bnr(load8<T>(b + ((size_t)ys0 * w + xs1) * ldsrc));
+  int yn = min(ys0 + 1, h - 1);
+  F8 nb0 = load8<T>(b + ((size_t)yn * w + xs) * ldsrc), nb1 = load8<T>(b + ((size_t)yn * w + xs1) * ldsrc);
+  for (int ys = ys0; ys < ys_end; ++ys) {
+    const F8 b0 = bnr(nb0), b1 = bnr(nb1);
+    yn = min(ys + 2, h - 1);                              // the next cell's bottom row: in flight while this cell is written
+    nb0 = load8<T>(b + ((size_t)yn * w + xs) * ldsrc);
+    nb1 = load8<T>(b + ((size_t)yn * w + xs1) * ldsrc);
+    int ja = 0, jb = H - 1;
+    if (sy > 0.f) {
+      ja = max(0, (int)floorf((float)ys / sy) - 1);
+      jb = min(H - 1, (int)ceilf(((float)ys + 1.f) / sy) + 1);
+    }
+    for (int j = ja; j <= jb; ++j) {
+      int y0, y1;
+      float ly0, ly1;
+      ac_src(sy, j, h, y0, y1, ly0, ly1);
+      if (y0 != ys) continue;
+      T* drow = dst + ((size_t)n * H + j) * W * lddst + choff + c;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (q < ncol) {
+          F8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.v[e] = lerp4(ly0, ly1, clx0[q], clx1[q], t0.v[e], t1.v[e], b0.v[e], b1.v[e]);
+          store8<T>(drow + (size_t)kcol[q] * lddst, o);
+        }
+    }
+    t0 = b0;
+    t1 = b1;
   }
 }
 
@@ -643,6 +730,25 @@ int mau_maxpool2x2_bwd_add(const void* x, int ldx, const void* dy, int lddy, con
   return check_launch("maxpool_bwd_kernel");
 }
 
+// Largest number of destination columns that share one left source column (host twin of ac_scale / ac_src: the same IEEE
+// float operations): resize_rows_kernel holds at most 3 per thread.
+static int resize_max_cols_per_cell(int in, int out) {
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  int best = 0, run = 0, prev = -1;
+  for (int k = 0; k < out; ++k) {
+    const float sf = scale * (float)k;
+    int i0 = (int)sf;
+    if (i0 > in - 1) i0 = in - 1;
+    run = i0 == prev ? run + 1 : 1;
+    prev = i0;
+    if (run > best) best = run;
+  }
+  return best;
+}
+static bool resize_rows_ok(int h, int w, int H, int W) {
+  return h <= H && w <= W && h <= 65535 && resize_max_cols_per_cell(w, W) <= 3;
+}
+
 int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst, int lddst, int choff, int dtype, int N,
                             int H, int W, int C, mau_stream_t stream) {
   MAU_REQUIRE(src && dst && N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, "resize_bilinear_fwd: bad arguments");
@@ -650,6 +756,16 @@ int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst,
   MAU_REQUIRE(ldsrc % 8 == 0 && lddst % 8 == 0 && choff % 8 == 0 && ldsrc >= C8 && lddst >= choff + C8, "resize_bilinear_fwd: bad ld/choff");
   MAU_REQUIRE(H <= 65535 && N <= 65535, "resize_bilinear_fwd: H and N must fit a grid dimension");
   static const bool no_cell = getenv("MAU_RESIZE_NO_CELL") != nullptr;              // (A/B timing)
+  static const bool no_rows = getenv("MAU_RESIZE_NO_ROWS") != nullptr;
+  if (resize_rows_ok(h, w, H, W) && !no_cell && !no_rows) {   // upsampling by <= ~2: a column of source cells per thread
+    const int xb = ceil_div(w * (C8 / 8), 256);
+    int RY = 8;
+    while (RY > 1 && (int64_t)xb * ceil_div(h, RY) * N < 1024) RY >>= 1;
+    dim3 gridr(xb, ceil_div(h, RY), N);
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((resize_rows_kernel<T, false>), gridr, dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff,
+                                         H, W, C8, (const float*)nullptr, (const float*)nullptr, C, RY));
+    return check_launch("resize_rows_kernel");
+  }
   if (h <= H && w <= W && h <= 65535 && !no_cell) {                                // upsampling: one thread per source cell
     dim3 gridc(ceil_div(w * (C8 / 8), 256), h, N);
     MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((resize_fwd_cell_kernel<T, false>), gridc, dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, H, W, C8,
@@ -667,6 +783,16 @@ int mau_resize_bilinear_bn_fwd(const void* y, int ldy, int h, int w, const float
   MAU_REQUIRE(h <= H && w <= W && h <= 65535 && N <= 65535, "resize_bilinear_bn_fwd: an upsampling (h <= H, w <= W), h and N within a grid dimension");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && lddst % 8 == 0 && choff % 8 == 0 && ldy >= C8 && lddst >= choff + C8, "resize_bilinear_bn_fwd: bad ld/choff");
+  static const bool no_rows = getenv("MAU_RESIZE_BN_CELL") != nullptr;             // (A/B timing: the one-cell-per-thread form)
+  if (!no_rows && resize_rows_ok(h, w, H, W)) {                                    // upsampling by <= ~2: a column of source cells per thread
+    const int xb = ceil_div(w * (C8 / 8), 256);
+    int RY = 8;
+    while (RY > 1 && (int64_t)xb * ceil_div(h, RY) * N < 1024) RY >>= 1;
+    dim3 gridr(xb, ceil_div(h, RY), N);
+    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((resize_rows_kernel<T, true>), gridr, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, h, w, (T*)dst, lddst, choff, H,
+                                         W, C8, scale, shift, C, RY));
+    return check_launch("resize_rows_kernel<BN>");
+  }
   dim3 gridc(ceil_div(w * (C8 / 8), 256), h, N);
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((resize_fwd_cell_kernel<T, true>), gridc, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, h, w, (T*)dst, lddst,
                                        choff, H, W, C8, scale, shift, C));

@@ -304,6 +304,7 @@ def _all_reduce_(t: torch.Tensor, st: BNState):
 _OVERLAP_WGRAD = os.environ.get("MAU_OVERLAP_WGRAD", "0") != "0"      # measured: ~1 % (profiles/r1), off by default
 _FUSED_REDUCE = os.environ.get("MAU_FUSED_REDUCE", "1") != "0"        # single-launch slab reductions (A/B switch; bit-identical)
 _FUSED_BN = os.environ.get("MAU_FUSED_BN", "1") != "0"                # BatchNorm passes fused with pool / head / upsample (A/B switch; bit-identical)
+_FUSED_UP = os.environ.get("MAU_FUSED_UP", "1") != "0"                # (the upsample member of the above, separately switchable)
 _SIDE_STREAMS = {}
 
 
@@ -459,8 +460,8 @@ class ConvBNReLU(torch.autograd.Function):
         # ---- the activation stage ----
         fused = _FUSED_BN
         fuse_head = fused and st.head is not None and Cout <= lib.mau_head_bn_max_channels()
-        fuse_up = fused and st.up_to is not None and H <= st.up_to[0] and W <= st.up_to[1]
-        a = pl = out = up = None
+        fuse_up = fused and _FUSED_UP and st.up_to is not None and H <= st.up_to[0] and W <= st.up_to[1]
+        a = pl = out = up = argidx = None
         if fuse_head:                                    # the head reads y and applies BatchNorm + ReLU on the fly: no activation tensor
             out = torch.empty((N, Co, H, W), **f32)
             call("mau_head_bn_fwd", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), w2.data_ptr(), hb.detach().data_ptr(),
@@ -475,8 +476,11 @@ class ConvBNReLU(torch.autograd.Function):
             lda = _ld(a)
             if st.pool and H >= 2 and W >= 2:
                 pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
+                # 2 bits per (window, channel): which pixel holds the maximum -- the routing of the pool's backward (fused with the
+                # BatchNorm backward passes, no activation is re-read for it)
+                argidx = torch.empty((N, H // 2, W // 2, ldy // 8), dtype=torch.int16, device=dev) if fused else None
                 call("mau_bn_relu_apply_pool", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), lda,
-                     pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
+                     pl.data_ptr(), ldy, argidx.data_ptr() if argidx is not None else None, code, N, H, W, Cout, stream)
             else:
                 call("mau_bn_relu_apply", y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), lda, code,
                      npix, Cout, stream)
@@ -493,7 +497,7 @@ class ConvBNReLU(torch.autograd.Function):
         ctx.up = (st.up_to, fuse_up) if st.up_to is not None else None
         # the activation is saved only where the backward still reads it: the unfused pool (arg-max) and the unfused head (dW)
         keep_a = a if ((pl is not None and not fused) or (st.head is not None and not fuse_head)) else None
-        ctx.save_for_backward(x, x1, emb, weight, y, scale, shift, mean, invstd, keep_a, w2, out)
+        ctx.save_for_backward(x, x1, emb, weight, y, scale, shift, mean, invstd, keep_a, w2, out, argidx)
         if st.head is not None:
             return out
         if st.up_to is not None:
@@ -504,7 +508,7 @@ class ConvBNReLU(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, da, dpl=None):
-        x, x1, emb, weight, y, scale, shift, mean, invstd, a, w2, out = ctx.saved_tensors
+        x, x1, emb, weight, y, scale, shift, mean, invstd, a, w2, out, argidx = ctx.saved_tensors
         st: BNState = ctx.st
         E, C1 = ctx.E, ctx.C1
         N, H, W, ldy = y.shape
@@ -537,7 +541,7 @@ class ConvBNReLU(torch.autograd.Function):
                 return sums, 0.0
             return sums, float(npix)
 
-        fused_pool = ctx.pooled and dpl is not None and _FUSED_BN and a is None
+        fused_pool = ctx.pooled and dpl is not None and argidx is not None
         if ctx.head is not None and ctx.head[3]:
             # ---- head + BatchNorm backward, two passes over y: da = W_head^T dz is recomputed from dout in both ----
             Co, tanh0, hshape, _ = ctx.head
@@ -560,7 +564,8 @@ class ConvBNReLU(torch.autograd.Function):
             # ---- pool + skip + BatchNorm backward, two passes over (y, dpl, dskip): no da tensor ----
             dpl = _as_nhwc(dpl)
             dsk = _as_nhwc(da) if da is not None else None
-            pargs = (y.data_ptr(), ldy, dpl.data_ptr(), _ld(dpl), dsk.data_ptr() if dsk is not None else None, _ld(dsk) if dsk is not None else 0)
+            pargs = (y.data_ptr(), ldy, dpl.data_ptr(), _ld(dpl), argidx.data_ptr(), dsk.data_ptr() if dsk is not None else None,
+                     _ld(dsk) if dsk is not None else 0)
             call("mau_pool_bn_bwd_reduce", *pargs, *cptrs, slab.data_ptr(), Cout, code, N, H, W, Cout, stream)
             sums_apply, count = finish_sums()
             call("mau_pool_bn_bwd_apply", *pargs, *cptrs, sums_apply.data_ptr(), count, dy.data_ptr(), ldy, code, N, H, W, Cout, stream)

@@ -206,7 +206,7 @@ def test_bn_relu_apply_pool_matches_two_passes(mau, dt, shape):
     p2 = torch.empty_like(p1)
     call("mau_bn_relu_apply", y.data_ptr(), ld, sc.data_ptr(), sh.data_ptr(), a1.data_ptr(), ld, code, N * H * W, C, st)
     call("mau_maxpool2x2_fwd", a1.data_ptr(), ld, p1.data_ptr(), ld, code, N, H, W, C, st)
-    call("mau_bn_relu_apply_pool", y.data_ptr(), ld, sc.data_ptr(), sh.data_ptr(), a2.data_ptr(), ld, p2.data_ptr(), ld, code, N, H, W, C, st)
+    call("mau_bn_relu_apply_pool", y.data_ptr(), ld, sc.data_ptr(), sh.data_ptr(), a2.data_ptr(), ld, p2.data_ptr(), ld, None, code, N, H, W, C, st)
     assert torch.equal(a1, a2) and torch.equal(p1, p2)
 
 
