@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256) void bn_relu_apply_pool_kernel(const T* __rest
     unsigned bits = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float a0 = (float)(T)o[0].v[j], a1 = (float)(T)o[1].v[j], a2 = (float)(T)o[2].v[j], a3 = (float)(T)o[3].v[j];
+      const float a0 = opaque((float)(T)opaque(o[0].v[j])), a1 = opaque((float)(T)opaque(o[1].v[j]));
+      const float a2 = opaque((float)(T)opaque(o[2].v[j])), a3 = opaque((float)(T)opaque(o[3].v[j]));
       unsigned arg = 0;
       float mx = a0;
       arg = a1 > mx ? 1u : arg;

@@ -21,7 +21,7 @@ namespace mau {
 
 template <typename T>
 __device__ __forceinline__ float round_to(float v) {
-  return (float)(T)v;
+  return opaque((float)(T)opaque(v));          // (a conversion and nothing else: mau_common.h, opaque)
 }
 
 // coefficients of 8 channels starting at c0 (zeros beyond C)

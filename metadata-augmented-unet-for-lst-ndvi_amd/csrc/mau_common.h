@@ -43,6 +43,15 @@ struct F8 {
   float v[8];
 };
 
+// fp16 <-> fp32 conversions stay conversions: the backend otherwise folds them into v_fma_mix_f32 / v_fma_mixlo_f16 wherever an
+// FMA is adjacent, and v_fma_mixlo_f16 does not round an f16-SUBNORMAL result like v_cvt_f16_f32 does (an exact tie came out
+// odd: 761 instead of 762 units of 2^-24) -- two kernels computing the same value then disagree depending on what the
+// compiler found next to the conversion.  The empty asm makes the fp32 value opaque at the conversion (no instruction).
+__device__ __forceinline__ float opaque(float v) {
+  asm("" : "+v"(v));
+  return v;
+}
+
 template <typename T>
 __device__ __forceinline__ F8 load8(const T* p);
 template <>
@@ -70,7 +79,7 @@ __device__ __forceinline__ F8 load8<f16>(const f16* p) {
   F8 r;
   f16x8 a = *reinterpret_cast<const f16x8*>(p);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+  for (int i = 0; i < 8; ++i) r.v[i] = opaque((float)a[i]);
   return r;
 }
 template <typename T>
@@ -98,7 +107,7 @@ template <>
 __device__ __forceinline__ void store8<f16>(f16* p, const F8& r) {
   f16x8 a;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = (f16)r.v[i];
+  for (int i = 0; i < 8; ++i) a[i] = (f16)opaque(r.v[i]);
   *reinterpret_cast<f16x8*>(p) = a;
 }
 
@@ -130,7 +139,7 @@ __device__ __forceinline__ F8 load8_nt<f16>(const f16* p) {
   F8 r;
   const f16x8 a = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+  for (int i = 0; i < 8; ++i) r.v[i] = opaque((float)a[i]);
   return r;
 }
 template <typename T>
@@ -158,7 +167,7 @@ template <>
 __device__ __forceinline__ void store8_nt<f16>(f16* p, const F8& r) {
   f16x8 a;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = (f16)r.v[i];
+  for (int i = 0; i < 8; ++i) a[i] = (f16)opaque(r.v[i]);
   __builtin_nontemporal_store(a, reinterpret_cast<f16x8*>(p));
 }
 

@@ -223,10 +223,10 @@ __global__ __launch_bounds__(256) void resize_fwd_cell_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float sc = coef(scale, c + e, C), sh = coef(shift, c + e, C);
-      v00.v[e] = (float)(T)fmaxf(fmaf(v00.v[e], sc, sh), 0.f);
-      v01.v[e] = (float)(T)fmaxf(fmaf(v01.v[e], sc, sh), 0.f);
-      v10.v[e] = (float)(T)fmaxf(fmaf(v10.v[e], sc, sh), 0.f);
-      v11.v[e] = (float)(T)fmaxf(fmaf(v11.v[e], sc, sh), 0.f);
+      v00.v[e] = opaque((float)(T)opaque(fmaxf(fmaf(v00.v[e], sc, sh), 0.f)));
+      v01.v[e] = opaque((float)(T)opaque(fmaxf(fmaf(v01.v[e], sc, sh), 0.f)));
+      v10.v[e] = opaque((float)(T)opaque(fmaxf(fmaf(v10.v[e], sc, sh), 0.f)));
+      v11.v[e] = opaque((float)(T)opaque(fmaxf(fmaf(v11.v[e], sc, sh), 0.f)));
     }
   }
   // destination rows / columns whose source index can be this cell (loose bounds, exact test below)
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(const T* __restrict__ 
     if constexpr (!BN) return v;
     F8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o.v[e] = (float)(T)fmaxf(fmaf(v.v[e], sc[e], sh[e]), 0.f);
+    for (int e = 0; e < 8; ++e) o.v[e] = opaque((float)(T)opaque(fmaxf(fmaf(v.v[e], sc[e], sh[e]), 0.f)));
     return o;
   };
   const float sy = ac_scale(h, H), sx = ac_scale(w, W);
