@@ -80,6 +80,14 @@ __device__ __forceinline__ void land(Frag& a, Frag& b) {
 }
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma_frag(const Frag& a, const Frag& b, f32x16 c) {
+#ifdef WG_HACK16        // TIMING ONLY (garbage results): the same operands through two v_mfma_f32_16x16x32 on quarters of the accumulator
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[4], c[5], c[6], c[7]}, q2 = {c[8], c[9], c[10], c[11]}, q3 = {c[12], c[13], c[14], c[15]};
+  q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), q0, 0, 0, 0);
+  q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), q1, 0, 0, 0);
+  // (a 32x32x16 MFMA = 16384 MACs = TWO 16x16x32; the other two quarters pass through)
+  return f32x16{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
+#endif
   if constexpr (F16) {
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.v), __builtin_bit_cast(f16x8, b.v), c, 0, 0, 0);
@@ -370,11 +378,28 @@ static int launch(const WgradP& p, int nsplit, hipStream_t st) {
 }
 }  // namespace wg2
 
+// Which kernel multiplies a layer: the 16x16x32 kernel (conv3x3_wgrad16.hip) works on 4 x 32 pixel tiles, this file's 32x32x16 kernel on
+// 8 x 16 ones.  The first is ~9 % faster per MFMA (clock), so it takes every layer unless its tiles waste more than that on
+// pixels outside the image (16-pixel-wide bottleneck images: twice the work).  MAU_WGRAD16=0: the 32x32x16 kernel everywhere.
+int launch_wgrad16(const WgradP& q, bool f16, int nsplit, int xcd_shift, hipStream_t st);
+struct WgVariant {
+  bool k16;
+  int th, tw;
+};
+static WgVariant wgrad_variant(int H, int W, bool addressable = true) {
+  const char* e = getenv("MAU_WGRAD16");
+  const bool allow = addressable && (e == nullptr || atoi(e) != 0);
+  const double a16 = (double)ceil_div(H, 4) * 4 * ceil_div(W, 32) * 32, a32 = (double)ceil_div(H, wg2::TH) * wg2::TH * ceil_div(W, wg2::TW) * wg2::TW;
+  if (allow && a16 <= 1.08 * a32) return {true, 4, 32};
+  return {false, wg2::TH, wg2::TW};
+}
+
 int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   const int CoutPad = round_up(Cout, 64), CinPad = round_up(Cin, 64);
   const int bco = (CoutPad % 128 == 0) ? 128 : 64;
   const int outTiles = (CoutPad / bco) * (CinPad / 64);
-  const int nTiles = N * ceil_div(H, wg2::TH) * ceil_div(W, wg2::TW);
+  const WgVariant v = wgrad_variant(H, W);
+  const int nTiles = N * ceil_div(H, v.th) * ceil_div(W, v.tw);
   // one workgroup per CU is resident (LDS / accumulator budget): pick the split count whose total
   // workgroup count fills whole rounds of the device's CUs, preferring fewer splits (less slab traffic) and
   // at least 4 pixel tiles per workgroup (pipeline fill).
@@ -405,10 +430,21 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
 
 int launch_wgrad_bf16_v2(const WgradP& p, bool f16, hipStream_t st) {
   const int nsplit = wgrad_bf16_v2_splits(p.N, p.H, p.W, p.Cout, p.Cin);
+  // the 16x16x32 kernel addresses its sources through buffer resources: every 64-channel block of input channels inside ONE source
+  // (x | x1 | broadcast embedding), 31-bit byte offsets
+  const long long px = (long long)p.N * p.H * p.W;
+  const bool addressable = (p.C1 == 0 || p.C0 % 64 == 0) && (p.E == 0 || (p.emb_lp != nullptr && (p.C0 + p.C1) % 64 == 0)) &&
+                           px * p.ldx * 2 < (1ll << 31) && px * p.ldx1 * 2 < (1ll << 31) && px * p.lddy * 2 < (1ll << 31);
+  const WgVariant v = wgrad_variant(p.H, p.W, addressable);
   WgradP q = p;
-  q.tilesX = ceil_div(p.W, wg2::TW);
-  q.tilesY = ceil_div(p.H, wg2::TH);
+  q.tilesX = ceil_div(p.W, v.tw);
+  q.tilesY = ceil_div(p.H, v.th);
   q.nTiles = p.N * q.tilesX * q.tilesY;
+  if (v.k16) {
+    const DeviceShape ds = device_shape();
+    const int xcd_shift = (wg2::wgrad_xcd_order() && ds.xcds > 1 && nsplit % ds.xcds == 0) ? ds.xcd_shift : 0;
+    return launch_wgrad16(q, f16, nsplit, xcd_shift, st);
+  }
 #ifndef WG_NS64
 #define WG_NS64 2
 #endif

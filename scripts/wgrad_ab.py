@@ -36,7 +36,7 @@ for name, cin, cout, h in layers:
     res = {}
     for rnd in range(2):
         for mode in ("0", "1"):
-            os.environ["MAU_WGRAD_XCD"] = mode
+            os.environ[os.environ.get("AB_VAR", "MAU_WGRAD_XCD")] = mode
             ns = lib.mau_conv3x3_wgrad_splits(code, N, H, W, cout, cin)
             acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, cout, cin), device="cuda")
             f_wg = lambda: call("mau_conv3x3_wgrad", x.data_ptr(), x.shape[-1], cin, None, None, 0, dy.data_ptr(), dy.shape[-1], cout, acc.data_ptr(), code, N, H, W, st)
