@@ -101,7 +101,9 @@ struct Sched16 {
   static constexpr int behind_a(int R) { return issued(3 * R) - issued(fstep(R)) > 15 ? 15 : issued(3 * R) - issued(fstep(R)); }
 };
 
-template <int BCO, int KG, bool F16>
+// MIXED: a 64-channel block of input channels may straddle the sources (tensor x | tensor x1 | broadcast embedding; channel counts off
+// the 64-channel grid): an X slot then issues one exec-masked DMA per source instead of one DMA.
+template <int BCO, int KG, bool F16, bool MIXED>
 __global__ __launch_bounds__((BCO / 64) * 4 * KG * 64) void wgrad16_kernel(WgradP p, int nsplit, int xcd_shift) {
   constexpr int WCO = BCO / 64;                      // co halves of 64
   constexpr int NW = WCO * 4 * KG;                   // waves: co half x ci quarter x row group
@@ -150,6 +152,10 @@ __global__ __launch_bounds__((BCO / 64) * 4 * KG * 64) void wgrad16_kernel(Wgrad
   const int xbytes = from_e ? p.N * p.E * 2 : p.N * p.H * p.W * xld * 2;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xsrc), 0, xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, p.N * p.H * p.W * p.lddy * 2, 0x00020000);
+  // (MIXED: one resource per source; the class of a lane's 8-channel chunk rides in bits 0-1 of its offset constant)
+  const __amdgpu_buffer_rsrc_t rs_m0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.N * p.H * p.W * p.ldx * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_m1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x1), 0, p.N * p.H * p.W * p.ldx1 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_m2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.emb_lp), 0, p.N * p.E * 2, 0x00020000);
 
   // ---- per-lane DMA slots.  Slot q = wave + j * NW: j < DY_J is a dY slot; then X slot q - DY_Q = (halo row R, 8-pixel group);
   // beyond TOT_Q a pad slot (zeros into the unused pixel group 40..47 of halo row q - TOT_Q).
@@ -177,8 +183,17 @@ __global__ __launch_bounds__((BCO / 64) * 4 * KG * 64) void wgrad16_kernel(Wgrad
       const int xq = q - DY_Q, R = xq / XGRP, grp = xq % XGRP;
       const int hx = grp * 8 + l8, pc = lane & 7;
       const int lc = pc ^ (key2(hx) << 1);
-      const int c = ci0 + 8 * lc - xcb;                                   // channel inside the source
-      if (hx < HVAL && c < xlim) s_lc[j] = (((R - 1) * p.W + (hx - 1)) * xld + c) * 2;     // (relative to the tile origin; may be negative)
+      if constexpr (!MIXED) {
+        const int c = ci0 + 8 * lc - xcb;                                 // channel inside the source
+        if (hx < HVAL && c < xlim) s_lc[j] = (((R - 1) * p.W + (hx - 1)) * xld + c) * 2;   // (relative to the tile origin; may be negative)
+      } else {
+        const int c = ci0 + 8 * lc, rel = (R - 1) * p.W + (hx - 1);
+        if (hx < HVAL) {                                                  // class 0: x (and lanes that read nothing), 1: x1, 2: embedding
+          if (c < p.C0 || (p.C1 == 0 && p.E == 0 && c < p.ldx)) s_lc[j] = (rel * p.ldx + c) * 2;
+          else if (c >= p.C0 && c < p.C0 + p.C1) s_lc[j] = ((rel * p.ldx1 + c - p.C0) * 2) | 1;
+          else if (c >= Ctot && c < Ctot + p.E) s_lc[j] = ((c - Ctot) * 2) | 2;
+        }
+      }
     }
   }
   // one wave-DMA (1 KiB); (n, ty0, tx0) wave-uniform.  ~6 vector instructions.
@@ -204,10 +219,20 @@ __global__ __launch_bounds__((BCO / 64) * 4 * KG * 64) void wgrad16_kernel(Wgrad
       const int xq = q - DY_Q, R = xq / XGRP, grp = xq % XGRP;           // (scalar; a pad slot's s_lc is NEVER)
       const int gy = ty0 + R - 1, gx = tx0 + grp * 8 + l8 - 1;
       const bool rowok = (unsigned)gy < (unsigned)p.H;
-      const int base = from_e ? n * p.E * 2 : ((n * p.H + ty0) * p.W + tx0) * xld * 2;
-      int voff = base + s_lc[j];
-      voff = (rowok && (unsigned)gx < (unsigned)p.W) ? voff : -1;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, ldst, 16, voff, 0, 0, 0);
+      if constexpr (!MIXED) {
+        const int base = from_e ? n * p.E * 2 : ((n * p.H + ty0) * p.W + tx0) * xld * 2;
+        int voff = base + s_lc[j];
+        voff = (rowok && (unsigned)gx < (unsigned)p.W) ? voff : -1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, ldst, 16, voff, 0, 0, 0);
+      } else {
+        // one DMA per source, each under the exec mask of its lanes (a masked lane writes nothing; class 0 also carries the lanes
+        // that read nothing: offset NEVER -> zeros).  Every wave issues all three: the DMA count per stage stays wave-uniform.
+        const int tpix = (n * p.H + ty0) * p.W + tx0, cls = s_lc[j] & 3, lc = s_lc[j] & ~3;
+        const bool inb = rowok && (unsigned)gx < (unsigned)p.W;
+        if (cls == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m0, ldst, 16, inb ? tpix * p.ldx * 2 + lc : -1, 0, 0, 0);
+        if (cls == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m1, ldst, 16, inb ? tpix * p.ldx1 * 2 + lc : -1, 0, 0, 0);
+        if (cls == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m2, ldst, 16, inb ? n * p.E * 2 + lc : -1, 0, 0, 0);
+      }
     }
   };
 
@@ -372,23 +397,29 @@ __global__ __launch_bounds__((BCO / 64) * 4 * KG * 64) void wgrad16_kernel(Wgrad
       }
 }
 
-template <int BCO, int KG, bool F16>
+template <int BCO, int KG, bool F16, bool MIXED>
 static int launch(const WgradP& p, int nsplit, int xcd_shift, hipStream_t st) {
   constexpr int NW = (BCO / 64) * 4 * KG;
   constexpr size_t stage = (size_t)(TH * TW * BCO * 2) + X_BYTES;
   constexpr size_t red = KG == 2 ? (size_t)(NW / 2) * 3 * 16 * 64 * sizeof(float) : 0;
   constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  MAU_LDS_ATTR(lds, &wgrad16_kernel<BCO, KG, F16>);
+  MAU_LDS_ATTR(lds, &wgrad16_kernel<BCO, KG, F16, MIXED>);
   dim3 grid(nsplit * (p.CoutPad / BCO) * (p.CinPad / BCI));
-  MAU_LAUNCH((wgrad16_kernel<BCO, KG, F16>), grid, dim3(NW * 64), lds, st, p, nsplit, xcd_shift);
+  MAU_LAUNCH((wgrad16_kernel<BCO, KG, F16, MIXED>), grid, dim3(NW * 64), lds, st, p, nsplit, xcd_shift);
   return check_launch("wgrad16_kernel");
 }
 }  // namespace wg3
 
-int launch_wgrad16(const WgradP& q, bool f16, int nsplit, int xcd_shift, hipStream_t st) {
-  if (q.CoutPad % 128 == 0) return f16 ? wg3::launch<128, 1, true>(q, nsplit, xcd_shift, st) : wg3::launch<128, 1, false>(q, nsplit, xcd_shift, st);
-  return f16 ? wg3::launch<64, 2, true>(q, nsplit, xcd_shift, st) : wg3::launch<64, 2, false>(q, nsplit, xcd_shift, st);
+template <bool F16>
+static int launch16(const WgradP& q, bool mixed, int nsplit, int xcd_shift, hipStream_t st) {
+  if (q.CoutPad % 128 == 0) return mixed ? wg3::launch<128, 1, F16, true>(q, nsplit, xcd_shift, st) : wg3::launch<128, 1, F16, false>(q, nsplit, xcd_shift, st);
+  return mixed ? wg3::launch<64, 2, F16, true>(q, nsplit, xcd_shift, st) : wg3::launch<64, 2, F16, false>(q, nsplit, xcd_shift, st);
+}
+
+// mixed: some 64-channel block of input channels straddles two sources
+int launch_wgrad16(const WgradP& q, bool f16, bool mixed, int nsplit, int xcd_shift, hipStream_t st) {
+  return f16 ? launch16<true>(q, mixed, nsplit, xcd_shift, st) : launch16<false>(q, mixed, nsplit, xcd_shift, st);
 }
 
 }  // namespace mau

@@ -381,7 +381,7 @@ static int launch(const WgradP& p, int nsplit, hipStream_t st) {
 // Which kernel multiplies a layer: the 16x16x32 kernel (conv3x3_wgrad16.hip) works on 4 x 32 pixel tiles, this file's 32x32x16 kernel on
 // 8 x 16 ones.  The first is ~9 % faster per MFMA (clock), so it takes every layer unless its tiles waste more than that on
 // pixels outside the image (16-pixel-wide bottleneck images: twice the work).  MAU_WGRAD16=0: the 32x32x16 kernel everywhere.
-int launch_wgrad16(const WgradP& q, bool f16, int nsplit, int xcd_shift, hipStream_t st);
+int launch_wgrad16(const WgradP& q, bool f16, bool mixed, int nsplit, int xcd_shift, hipStream_t st);
 struct WgVariant {
   bool k16;
   int th, tw;
@@ -430,11 +430,11 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
 
 int launch_wgrad_bf16_v2(const WgradP& p, bool f16, hipStream_t st) {
   const int nsplit = wgrad_bf16_v2_splits(p.N, p.H, p.W, p.Cout, p.Cin);
-  // the 16x16x32 kernel addresses its sources through buffer resources: every 64-channel block of input channels inside ONE source
-  // (x | x1 | broadcast embedding), 31-bit byte offsets
+  // the 16x16x32 kernel addresses its sources through buffer resources (31-bit byte offsets); a 64-channel block of input channels
+  // that straddles two sources (x | x1 | broadcast embedding off the 64-channel grid) takes its MIXED loader
   const long long px = (long long)p.N * p.H * p.W;
-  const bool addressable = (p.C1 == 0 || p.C0 % 64 == 0) && (p.E == 0 || (p.emb_lp != nullptr && (p.C0 + p.C1) % 64 == 0)) &&
-                           px * p.ldx * 2 < (1ll << 31) && px * p.ldx1 * 2 < (1ll << 31) && px * p.lddy * 2 < (1ll << 31);
+  const bool addressable = px * p.ldx * 2 < (1ll << 31) && px * p.ldx1 * 2 < (1ll << 31) && px * p.lddy * 2 < (1ll << 31) && (p.E == 0 || p.emb_lp != nullptr);
+  const bool mixed = !((p.C1 == 0 || p.C0 % 64 == 0) && (p.E == 0 || (p.C0 + p.C1) % 64 == 0));
   const WgVariant v = wgrad_variant(p.H, p.W, addressable);
   WgradP q = p;
   q.tilesX = ceil_div(p.W, v.tw);
@@ -443,7 +443,7 @@ int launch_wgrad_bf16_v2(const WgradP& p, bool f16, hipStream_t st) {
   if (v.k16) {
     const DeviceShape ds = device_shape();
     const int xcd_shift = (wg2::wgrad_xcd_order() && ds.xcds > 1 && nsplit % ds.xcds == 0) ? ds.xcd_shift : 0;
-    return launch_wgrad16(q, f16, nsplit, xcd_shift, st);
+    return launch_wgrad16(q, f16, mixed, nsplit, xcd_shift, st);
   }
 #ifndef WG_NS64
 #define WG_NS64 2
