@@ -72,6 +72,8 @@ class ConvTimer:
                 e0.record()
                 orig(name, *args)
                 e1.record()
+                # algorithmic bytes of the launch: X and dY read once (16-bit), dW written once (fp32)
+                self.wbytes = getattr(self, "wbytes", 0.0) + (Cin + Cout) * N * H * W * 2.0 + 9.0 * Cin * Cout * 4.0
                 self.wrecords.append((e0, e1, conv_flops(N, H, W, Cin, Cout)))
             else:
                 orig(name, *args)
@@ -87,7 +89,12 @@ class ConvTimer:
         return dict(launches=len(ms), total_ms=sum(ms), total_flop=sum(fl))
 
     def summary(self):
-        return self._sum(self.records)
+        r = self._sum(self.records)
+        if r is not None:      # the launches of >= 0.3 ms alone (what the PMC figures of profiles/ are quoted on)
+            long = [(a.elapsed_time(b), f) for a, b, f in self.records if a.elapsed_time(b) >= 0.3]
+            r["long_launches"] = len(long)
+            r["long_tflops"] = sum(f for _, f in long) / max(1e-9, sum(t for t, _ in long) * 1e-3) / 1e12 if long else None
+        return r
 
     def wgrad_summary(self):
         return self._sum(self.wrecords)
@@ -342,7 +349,8 @@ def main():
                 "timing": timing_pass,
                 # PMC figures of the >= 0.3 ms dispatches only (GRBM_GUI_ACTIVE reads high on shorter ones): frac ~ busy x clock / 2.4 GHz
                 "mfma_busy": rec.get("mfma_busy_long"), "clock_ghz": rec.get("clock_ghz_long"),
-                "frac_long_dispatches": rec.get("frac_long"),
+                "frac_executed_long_dispatches_pmc": rec.get("frac_long"),
+                "frac_long_launches_live": round(conv["long_tflops"] / peak, 4) if conv.get("long_tflops") else None,
                 "hbm_gbps": round(traffic / (conv["total_ms"] * 1e-3 / conv["launches"]) / 1e9, 1) if traffic else None}
     if wg is not None:
         wach = wg["total_flop"] / (wg["total_ms"] * 1e-3) / 1e12
@@ -350,8 +358,9 @@ def main():
         wflop = wg["total_flop"] / wg["launches"]
         roofline["wgrad"] = {"kernel": "wgrad_bf16_kernel", "achieved": round(wach, 2), "frac": round(wach / peak, 4),
                              "launches": wg["launches"], "avg_launch_ms": round(wg["total_ms"] / wg["launches"], 4),
-                             "traffic": wrec.get("hbm_bytes_per_launch_pmc"), "algorithmic_bytes": wrec.get("algorithmic_bytes_per_launch"),
-                             "traffic_ratio": wrec.get("traffic_ratio"), "flop_per_launch_avg": wflop}
+                             "traffic": wrec.get("hbm_bytes_per_launch_pmc"), "algorithmic_bytes": round(timer.wbytes / wg["launches"]),
+                             "traffic_ratio": round(wrec["hbm_bytes_per_launch_pmc"] / (timer.wbytes / wg["launches"]), 3) if wrec.get("hbm_bytes_per_launch_pmc") else None,
+                             "mfma_busy": wrec.get("mfma_busy_long"), "clock_ghz": wrec.get("clock_ghz_long"), "flop_per_launch_avg": wflop}
     result = {
         "metric": ("inference images/sec" if args.infer else "train images/sec") + f" ({S}x{S}x{args.channels}->2 {'U-Net' if args.model_type == 'unet' else 'U-Net++'}, B={B}/GPU)",
         "value": round(B * world * args.steps / elapsed, 2),

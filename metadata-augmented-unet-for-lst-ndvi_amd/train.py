@@ -79,8 +79,10 @@ def main(device: str = "", wandblog: bool = False, n_trials: int = 1, force_stud
 def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study_name: bool = False,
         temporal_embeddings: bool = True, metadata_embeddings: bool = True, study_name: str = "urban-predictor",
         model_type: str = "unet++", jobid: str = "", epochs: Optional[int] = None, steps_per_epoch: int = 20,
-        precision: str = "bf16", val_batches: int = 2, graph: bool = True):
-    """Body of the CLI as a function; returns {'best' (validation loss), 'model', 'optimizer', 'checkpoint_path', 'history'}."""
+        precision: str = "bf16", val_batches: int = 2, graph: bool = True, force_dist: bool = False):
+    """Body of the CLI as a function; returns {'best' (validation loss), 'model', 'optimizer', 'checkpoint_path', 'history'}.
+    ``force_dist``: take the data-parallel path (SyncBN + GradSync over the default process group) even with one rank -- the
+    one-GPU rehearsal of the RCCL code path (tests/test_gpu_dist_rehearsal.py)."""
     assert model_type in ["unet", "unet++"], "model_type must be 'unet' or 'unet++'"          # src/train.py:78
     if not force_study_name:                                                                  # src/train.py:79-87
         study_name += "-emb" if temporal_embeddings and metadata_embeddings else "-tempemb" if temporal_embeddings \
@@ -116,8 +118,8 @@ def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study
     else:
         raise NotImplementedError(f"Loss {cfg.loss} not implemented.")
     sync = None
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world > 1 or (force_dist and dist.is_available() and dist.is_initialized()):
         model.set_sync_bn(dist.group.WORLD)
         sync = GradSync(model)
     hyper = build_hyperparameters(cfg, model_type, temporal_embeddings, metadata_embeddings,

@@ -2,7 +2,7 @@
 """Turn the raw rocprofv3 output of scripts/profile.sh (gpurun_out/prof_<tag>/) into the committed summaries:
    profiles/<round>/<key>/kernel_stats_bench_steps3.csv, pmc_per_kernel.csv, dominant_kernel_summary.json
    and the entry <key> of profiles/<round>/pmc_summary.json that bench.py reads (roofline.traffic / mfma_busy).
-Usage: scripts/summarize_profile.py gpurun_out/prof_<tag> profiles/r2 <workload key as bench.py's workload_key()>"""
+Usage: scripts/summarize_profile.py gpurun_out/prof_<tag> profiles/r3 <workload key as bench.py's workload_key()>"""
 import collections, csv, glob, json, os, shutil, sys
 
 src, root, key = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -15,6 +15,7 @@ total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
 
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
+per_disp = []                       # dispatches of the pass that carries MFMA-busy AND GRBM_GUI_ACTIVE: (kernel, duration ns, counters)
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
@@ -22,10 +23,17 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not fs:
         continue
     f = fs[-1]                      # (a re-profiled tag keeps older passes next to the new one: the newest pass only)
+    byd = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
         k, c = r["Kernel_Name"], r["Counter_Name"]
         agg[k][c] += float(r["Counter_Value"])
         disp[k][c].add(r["Dispatch_Id"])
+        byd[r["Dispatch_Id"]][c] = float(r["Counter_Value"])
+        byd[r["Dispatch_Id"]]["_k"] = k
+    if any("GRBM_GUI_ACTIVE" in v and "SQ_VALU_MFMA_BUSY_CYCLES" in v for v in byd.values()):
+        tr = f.replace("counter_collection.csv", "kernel_trace.csv")
+        dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tr))} if os.path.exists(tr) else {}
+        per_disp = [(v["_k"], dur.get(i, 0), v) for i, v in byd.items()]
 with open(os.path.join(dst, "pmc_per_kernel.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "counter", "dispatches", "sum", "per_dispatch"])
@@ -55,6 +63,23 @@ def family(pred):
         out["lds_bank_conflict_fraction"] = cnt["SQ_LDS_BANK_CONFLICT"] / cnt["SQ_LDS_IDX_ACTIVE"]
     if cnt.get("TCC_HIT_sum"):
         out["l2_hit_rate"] = cnt["TCC_HIT_sum"] / (cnt["TCC_HIT_sum"] + cnt["TCC_MISS_sum"])
+    # Dispatches of >= 0.3 ms only, MFMA-busy and clock from ONE pass (GRBM_GUI_ACTIVE / 8 / time reads high on shorter dispatches,
+    # MI355X_MICROARCH.md 'DVFS give-back'): busy = MFMA-busy cycles / (SIMD cycles), clock = GUI cycles / time, and the fraction of
+    # the 2.5 PFLOP/s peak these dispatches EXECUTE (padding included; 1024 FLOP per MFMA-busy cycle for both bf16 shapes) -- which
+    # must equal busy x clock / 2.4 GHz (peak = 1024 SIMDs x 1024 FLOP x 2.4 GHz = 2.517 PF vs the nominal 2.5: 0.7 %).
+    long = [(d, v) for k, d, v in per_disp if pred(k) and d >= 300000 and "GRBM_GUI_ACTIVE" in v]
+    if long:
+        busy_c = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for _, v in long)
+        gui = sum(v["GRBM_GUI_ACTIVE"] for _, v in long) / 8.0
+        t = sum(d for d, _ in long) * 1e-9
+        out["long_dispatches"] = len(long)
+        out["long_share_of_family_time"] = sum(d for d, _ in long) / max(1.0, sum(d for k, d, v in per_disp if pred(k)))
+        out["mfma_busy_long"] = busy_c / (gui * 256 * 4)
+        out["clock_ghz_long"] = gui / t / 1e9
+        out["frac_executed_long"] = busy_c * 1024 / t / 2.5e15
+        recon = out["mfma_busy_long"] * out["clock_ghz_long"] / 2.4
+        assert abs(recon - out["frac_executed_long"]) <= 0.05 * out["frac_executed_long"], (recon, out["frac_executed_long"])
+        out["busy_x_clock_over_2p4"] = recon
     return out
 
 
@@ -64,7 +89,7 @@ summary = {
     "correction": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced reads incl. LDS-DMA; WRITE_SIZE is exact for 16-B stores (MI355X_MICROARCH.md, HBM section)",
     "mfma_busy_fraction": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs)",
     "conv3x3_bf16_kernel (dominant: forward + data gradient)": family(lambda n: "conv3x3_bf16_kernel" in n),
-    "wgrad_bf16_kernel": family(lambda n: "wgrad_bf16_kernel" in n),
+    "wgrad kernels (wgrad16_kernel + wgrad_bf16_kernel)": family(lambda n: "wgrad16_kernel" in n or "wgrad_bf16_kernel" in n),
 }
 json.dump(summary, open(os.path.join(dst, "dominant_kernel_summary.json"), "w"), indent=1)
 dom = summary["conv3x3_bf16_kernel (dominant: forward + data gradient)"]
@@ -73,7 +98,9 @@ allk = json.load(open(pj)) if os.path.exists(pj) else {}
 allk[key] = {"hbm_bytes_per_launch": dom.get("hbm_bytes_per_launch_pmc"), "mfma_busy": dom.get("mfma_busy_fraction"),
              "avg_launch_us_rocprof": dom["avg_launch_us_rocprof"], "launches": dom["launches"], "l2_hit_rate": dom.get("l2_hit_rate"),
              "lds_bank_conflict_fraction": dom.get("lds_bank_conflict_fraction"), "command": cmd,
-             "wgrad": summary["wgrad_bf16_kernel"]}
+             "mfma_busy_long": dom.get("mfma_busy_long"), "clock_ghz_long": dom.get("clock_ghz_long"), "frac_long": dom.get("frac_executed_long"),
+             "long_dispatches": dom.get("long_dispatches"), "long_share_of_family_time": dom.get("long_share_of_family_time"),
+             "wgrad": summary["wgrad kernels (wgrad16_kernel + wgrad_bf16_kernel)"]}
 json.dump(allk, open(pj, "w"), indent=1)
 print(json.dumps(summary, indent=1))
 top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:12]

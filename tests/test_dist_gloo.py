@@ -2,8 +2,12 @@
 
  * GradSync: bucketed, hook-driven gradient averaging == single-process gradients on the joint batch,
    including a parameter that never receives a gradient.
- * SyncBN exchange: the [sum | sum of squares] all-reduce used by functional.ConvBNReLU reproduces the
-   reference's single-device statistics on the joint batch (fixture G8, generated from the reference).
+ * SyncBN exchange: the [sum | sum of squares | local pixel count] all-reduce of functional.ConvBNReLU (the message layout of
+   mau_bn_stats_sums_f64 / mau_bn_finalize_train with count = 0) reproduces the reference's single-device statistics on the
+   joint batch with RAGGED per-rank batches (fixture G8, generated from the reference).  The kernels that produce the sums
+   and apply the result need a GPU: that path (real module, kernels, hooks; 2 ranks, ragged batches) is
+   tests/test_gpu_dist_rehearsal.py; here the exchange itself (product code: functional._all_reduce_ -> dist.all_reduce_sum)
+   and the count convention run on CPU over gloo.
 """
 import os
 import tempfile
@@ -78,16 +82,17 @@ def _worker_syncbn(rank, init_file, out_dir):
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=WORLD)
     d = load_npz("g8_syncbn.npz")
     sd0 = sub(d, "sd0")
-    x = t(d["x"]).chunk(WORLD)[rank]
+    xa = t(d["x"])
+    x = xa[:xa.shape[0] - 1] if rank == 0 else xa[xa.shape[0] - 1:]          # ragged: all but one sample | one sample
     y1 = torch.nn.functional.conv2d(x, sd0["conv1.weight"], sd0["conv1.bias"], padding=1)
     C = y1.shape[1]
-    # what the conv epilogue + slab reduce produce on each rank: [sum(y) | sum(y^2)] in fp64
-    sums = torch.cat([y1.double().sum(dim=(0, 2, 3)), (y1.double() ** 2).sum(dim=(0, 2, 3))])
+    # what the conv epilogue + mau_bn_stats_sums_f64 produce on each rank: [sum(y) | sum(y^2) | local pixel count] in fp64
+    sums = torch.cat([y1.double().sum(dim=(0, 2, 3)), (y1.double() ** 2).sum(dim=(0, 2, 3)), torch.tensor([float(y1.numel() // C)], dtype=torch.float64)])
     st = BNState(training=True, C0=x.shape[1], group=dist.group.WORLD, world=WORLD)
     _all_reduce_(sums, st)                                   # the product's exchange
-    count = float(y1.numel() // C * st.world)                # equal per-rank pixel counts (documented assumption)
+    count = float(sums[2 * C])                               # the global count travelled with the sums (mau_bn_finalize_train, count = 0)
     mean = sums[:C] / count
-    var = sums[C:] / count - mean * mean
+    var = sums[C:2 * C] / count - mean * mean
     scale = sd0["bn1.weight"].double() / torch.sqrt(var + 1e-5)
     shift = sd0["bn1.bias"].double() - mean * scale
     a1 = torch.relu(y1.double() * scale[None, :, None, None] + shift[None, :, None, None]).float()

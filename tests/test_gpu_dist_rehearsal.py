@@ -26,13 +26,17 @@ net = mau_amd.UrbanPredictor(**kw).cuda().set_precision("fp32").train()
 g = torch.Generator().manual_seed(3)
 x = torch.randn(4, 6, 32, 32, generator=g); ts = torch.randn(4, 10, generator=g); md = torch.randn(4, 4, generator=g); tgt = torch.randn(4, 2, 32, 32, generator=g)
 if world > 1:
-    sl = slice(rank * 2, rank * 2 + 2)
+    # RAGGED local batches (3 + 1): the pixel count travels with the BatchNorm sums, so the ranks still agree on the global moments;
+    # the MSE criterion is a mean over the local batch, so each rank weights its loss by its share of the global batch (what a
+    # DistributedSampler with equal shards makes implicit)
+    sl = slice(0, 3) if rank == 0 else slice(3, 4)
     x, ts, md, tgt = x[sl], ts[sl], md[sl], tgt[sl]
     net.set_sync_bn(dist.group.WORLD)
     sync = GradSync(net, bucket_bytes=64 << 10)
 x, ts, md, tgt = x.cuda(), ts.cuda(), md.cuda(), tgt.cuda()
 out = net(x, ts, md)
 loss = mau_amd.compute_loss_mse(out, tgt)["total"]
+if world > 1: loss = loss * (x.shape[0] * world / 4.0)        # GradSync averages over ranks: local mean x (local share x world) = global mean
 if world > 1: sync.begin()
 loss.backward()
 if world > 1: sync.finish()
@@ -104,6 +108,35 @@ for prec in ("fp32", "bf16"):
         torch.cuda.synchronize()
         res[(prec, synced)] = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if "running" in k}
         res[(prec, synced)].update({"grad." + k: p.grad.float().cpu() for k, p in net.named_parameters() if p.grad is not None})
+# U-Net++ with the temporal branch: the LSTM runs on its side stream under the process group (GradSync waits for every stream that
+# produced a gradient of a bucket); 3 steps with fused AdamW, synced vs plain, must agree
+kw2 = dict(model_type="unet++", spatial_channels=6, seq_len=24, temporal_dim=16, meta_features=4, meta_dim=16, lstm_dim=24, out_channels=2, base_filters=16)
+ts2 = torch.randn(4, 24, generator=g).cuda()
+for synced in (False, True):
+    torch.manual_seed(1)
+    net = mau_amd.UrbanPredictor(**kw2).cuda().set_precision("bf16").train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, fused=True)
+    sync = None
+    if synced:
+        net.set_sync_bn(dist.group.WORLD)
+        sync = GradSync(net, dist.group.WORLD, bucket_bytes=256 << 10)
+    for step in range(3):
+        loss = mau_amd.compute_loss_mse(net(x, ts2, md), tgt)["total"]
+        if sync: sync.begin()
+        loss.backward()
+        if sync: sync.finish()
+        if sync: assert all(p.grad is None or p.grad.data_ptr() == p._mau_grad_slot.data_ptr() for p in net.parameters())   # gradients live in the arena
+        opt.step(); opt.zero_grad()
+    torch.cuda.synchronize()
+    res[("unet++", synced)] = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if v.is_floating_point()}
+# the training driver on the data-parallel path (SyncBN + GradSync + eager step + validate() + best-validation checkpoint)
+from mau_amd import train
+from mau_amd.config import CONFIG
+CONFIG.MODELS_DIR = os.environ["MAU_OUT"]
+r = train.run(device="gpu", temporal_embeddings=False, metadata_embeddings=True, model_type="unet", jobid="rccl", epochs=2, steps_per_epoch=2,
+              precision="bf16", val_batches=1, force_dist=True)
+assert r["checkpoint_path"] and os.path.exists(r["checkpoint_path"]) and len(r["history"]) == 2 and all(v == v for e in r["history"] for v in e)
+res["train_best"] = torch.tensor(r["best"])
 torch.save(res, os.path.join(os.environ["MAU_OUT"], "rccl1.pt"))
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -126,6 +159,13 @@ def test_rccl_collectives_one_rank_group(tmp_path):
         for k in a:
             err = float((a[k] - b[k]).abs().max())
             assert err < tol * float(a[k].abs().max()) or err < 1e-6, (prec, k, err)
+    # U-Net++ (LSTM side stream under the group, gradients written into the arena), 3 AdamW steps: parameters stay together
+    a, b = res[("unet++", False)], res[("unet++", True)]
+    assert a.keys() == b.keys()
+    num = sum(float(((a[k] - b[k]).double() ** 2).sum()) for k in a)
+    den = sum(float((a[k].double() ** 2).sum()) for k in a)
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+    assert float(res["train_best"]) < float("inf")
 
 
 def test_bench_self_launches_two_ranks(tmp_path):
