@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--model-type", default="unet", choices=["unet", "unet++"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of mau_amd.AdamW (same update rule)")
     ap.add_argument("--no-graph", action="store_true", help="launch the train step kernel by kernel from Python instead of replaying "
                                                             "its hipGraph (always so for N > 1 and for --infer)")
     ap.add_argument("--infer", action="store_true", help="inference-only images/s (eval mode, no_grad): BASELINE configs[4]")
@@ -213,7 +214,10 @@ def main():
     ts = torch.randn(B, args.seq_len, generator=g).to(dev)
     md = torch.randn(B, args.meta, generator=g).to(dev)
     tgt = torch.randn(B, 2, S, S, generator=g).to(dev)
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-3, fused=True)   # conf/config.yaml:41,48,52
+    # AdamW lr 1e-4 wd 1e-3 (conf/config.yaml:41,48,52): mau_amd.AdamW = torch.optim.AdamW's update with the re-pack of the convolution
+    # weights fused into the same kernel (--torch-adamw: torch's fused AdamW + a separate multi-tensor pack launch)
+    opt = (torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-3, fused=True) if args.torch_adamw
+           else mau_amd.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-3))
     sync = None
     if world > 1:
         if not args.no_sync_bn:

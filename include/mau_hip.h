@@ -315,6 +315,19 @@ int mau_linear_fwd(const float* x, const float* w, const float* b, float* out, i
 int mau_linear_bwd(const float* x, const float* w, const float* dout, float* dx, float* dw, float* db, int N, int F,
                    int D, mau_stream_t stream);
 
+/* ---- optimizer: torch.optim.AdamW (src/train.py:213-214,255) on every 3x3 convolution weight of a network, fused with the
+ *      re-pack of the updated weights (mau_conv3x3_pack_weights): ONE launch, each parameter streamed once ----
+ * Table rows (mau_adamw_pack_desc_bytes() each, filled on the HOST by mau_adamw_pack_desc_fill, copied to the device by the
+ * caller): w OIHW fp32 (Cout,Cin,3,3) updated in place, grad, exp_avg, exp_avg_sq of the same shape, wf / wd = the packs of
+ * mau_conv3x3_pack_weights for `dtype` (both NULL: no pack); tile0 = *next_tile_host of the previous row (0 for row 0).
+ * step: DEVICE float, the step count t of this update (already incremented).  p <- p(1 - lr*wd); m <- b1 m + (1-b1) g;
+ * v <- b2 v + (1-b2) g^2; p <- p - lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
+size_t mau_adamw_pack_desc_bytes(void);
+int mau_adamw_pack_desc_fill(void* descs_host, int index, float* w, const float* grad, float* exp_avg, float* exp_avg_sq,
+                             void* wf, void* wd, int Cout, int Cin, int tile0, int* next_tile_host);
+int mau_adamw_pack_step(const void* descs, int n, int total_tiles, int dtype, const float* step, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, mau_stream_t stream);
+
 /* ---- loss: F.mse_loss (src/utils/losses.py:27-39) -------------------------- */
 /* loss[0] = mean((out-tgt)^2) (fp64 accumulation, fixed order); dout (optional) = 2*(out-tgt)/n;
  * partial: fp64 workspace of mau_mse_blocks(n) elements. */

@@ -10,9 +10,10 @@ from .losses import (compute_loss_l1_grad_ssim, compute_loss_mse, compute_loss_m
                      gradient_loss)
 from .inference import GraphedInference  # noqa: F401
 from .train_graph import GraphedTrainStep  # noqa: F401
+from .optim import AdamW  # noqa: F401
 from .functional import mark_params_updated  # noqa: F401
 from . import data                      # noqa: F401  (input pipeline: compact tiles, device-side one-hot + RandomFlip)
 
 __all__ = ["UrbanPredictor", "UrbanPredictor_unet", "UrbanPredictor_unetpp", "VGGBlock", "MetadataEncoder",
            "TemporalEncoder", "compute_loss_mse", "compute_loss_mse_gradient", "compute_loss_l1_grad_ssim", "gradient_loss",
-           "GraphedInference", "GraphedTrainStep", "mark_params_updated"]
+           "GraphedInference", "GraphedTrainStep", "AdamW", "mark_params_updated"]

@@ -89,6 +89,9 @@ PROTOTYPES = {
     "mau_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "mau_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "mau_linear_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "mau_adamw_pack_desc_bytes": (_sz, []),
+    "mau_adamw_pack_desc_fill": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "mau_adamw_pack_step": (_i, [_p, _i, _i, _i, _p, _f, _f, _f, _f, _f, _p]),
     "mau_mse_blocks": (_i, [_i64]),
     "mau_l1_gradient_blocks": (_i, [_i64]),
     "mau_l1_gradient_loss": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i, _i, _i, _p]),

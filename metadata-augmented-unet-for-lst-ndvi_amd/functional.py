@@ -150,6 +150,7 @@ class PackGroup:
     def __init__(self):
         self.params: List[torch.Tensor] = []
         self._state = {}
+        self.fresh_after_step = -1        # optimizer-step generation whose packs optim.AdamW wrote together with the update
 
     def add(self, w: torch.Tensor):
         if not any(w is q for q in self.params):
@@ -179,7 +180,9 @@ class PackGroup:
             st = self._state[code] = self._build(code, ptrs)
         key = (_GENERATION[0], tuple(w._version for w in self.params))
         if st["key"] != key:
-            call("mau_conv3x3_pack_weights_multi", st["table"].data_ptr(), len(self.params), st["tiles"], code, _stream())
+            # (optim.AdamW has already written the packs of this generation while it updated the weights: nothing to launch)
+            if not (self.fresh_after_step == _GENERATION[0] and st["key"] is not None and st["key"][1] == key[1] and len(self._state) == 1):
+                call("mau_conv3x3_pack_weights_multi", st["table"].data_ptr(), len(self.params), st["tiles"], code, _stream())
             st["key"] = key
             for w, f, d in zip(self.params, st["wf"], st["wd"]):
                 w._mau_pack = [(key[0], w._version, w.data_ptr(), code), f, d]

@@ -24,6 +24,7 @@ from .checkpoint import build_hyperparameters, save_checkpoint
 from .config import CONFIG
 from .dist import GradSync, init_process_group_from_env
 from .model import UrbanPredictor
+from .optim import AdamW
 from .train_graph import GraphedTrainStep
 
 app = typer.Typer(add_completion=False)
@@ -105,8 +106,8 @@ def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study
         optimizer = torch.optim.SGD(model.parameters(), lr=cfg.learning_rate, momentum=cfg.momentum)
     elif cfg.optimizer == "Adam":
         optimizer = torch.optim.Adam(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
-    elif cfg.optimizer == "AdamW":      # one fused multi-tensor launch per step (the kernel bench.py times)
-        optimizer = torch.optim.AdamW(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay, fused=True)
+    elif cfg.optimizer == "AdamW":      # torch.optim.AdamW's rule; the convolution weights' update + re-pack is one kernel (optim.py)
+        optimizer = AdamW(model.parameters(), lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
     else:
         raise NotImplementedError(f"Optimizer {cfg.optimizer} not implemented.")
     if cfg.loss == "mse":                                                                     # src/train.py:218-225

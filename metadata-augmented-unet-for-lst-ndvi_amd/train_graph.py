@@ -25,6 +25,7 @@ from typing import Callable, Optional, Sequence
 import torch
 
 from . import functional as F_
+from .optim import AdamW as _AdamW
 
 
 def _make_capturable(optimizer: torch.optim.Optimizer):
@@ -56,6 +57,7 @@ class GraphedTrainStep:
         self._in: Optional[Sequence[torch.Tensor]] = None
         self.loss: Optional[torch.Tensor] = None
         self.outputs: Optional[torch.Tensor] = None
+        self._groups, self._self_packing, self._expect_gen = [], False, -1
         _make_capturable(optimizer)
 
     # ------------------------------------------------------------------ #
@@ -79,7 +81,13 @@ class GraphedTrainStep:
         else:
             self._in = list(batch)
         self.optimizer.zero_grad(set_to_none=True)        # the captured backward ASSIGNS the gradients (static buffers of the graph)
-        F_.mark_params_updated()                          # the captured forward starts with the (captured) weight re-pack
+        # Who re-packs the convolution weights?  torch's optimizers: the captured forward starts with the (captured) multi-tensor
+        # re-pack.  optim.AdamW writes the packs together with the update: the captured step then contains NO separate pack -- the
+        # forward of replay k reads what the optimizer of replay k - 1 (or of the last warm-up step) wrote.
+        self._groups = [m._pack_group for m in self.model.modules() if hasattr(m, "_pack_group")]
+        self._self_packing = isinstance(self.optimizer, _AdamW)
+        if not self._self_packing:
+            F_.mark_params_updated()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         try:
@@ -112,7 +120,18 @@ class GraphedTrainStep:
                 dst.copy_(src, non_blocking=True)
         elif any(a.data_ptr() != b.data_ptr() or a.shape != b.shape for a, b in zip(self._in, batch)):
             raise ValueError("GraphedTrainStep(copy_inputs=False): pass the tensors of the captured call (fill them in place)")
+        if self._self_packing and F_._GENERATION[0] != self._expect_gen:
+            # something outside changed parameters since the last replay (another optimizer's step, mark_params_updated(), an eager
+            # step): the graph holds no pack launch of its own, so the packs are brought up to date before it runs
+            for pg in self._groups:
+                for code in list(pg._state):
+                    pg.ensure(code)
         self.graph.replay()
-        # the replay changed every parameter behind Python's back: eager forwards that follow (validation) must re-pack
+        # the replay changed every parameter behind Python's back: eager forwards that follow (validation) must re-pack -- unless
+        # the captured optimizer already wrote the packs of the new weights
         F_.mark_params_updated()
+        if self._self_packing:
+            for pg in self._groups:
+                pg.fresh_after_step = F_._GENERATION[0]
+        self._expect_gen = F_._GENERATION[0]
         return self.loss
