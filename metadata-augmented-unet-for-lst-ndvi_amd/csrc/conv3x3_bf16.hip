@@ -479,11 +479,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
     // at most 4 * MT operations are outstanding covers the DMAs without waiting out the stores' HBM write round trip
     // (with vmcnt(0) every item of a short-K layer paid it).  (A flag tested at the loop head made the compiler peel the
     // first iteration, with register reloads and full vmcnt(0) drains inside the peeled copy.)
+#ifndef MAU_CONV_ABL_NOWAIT
 #ifndef MAU_CONV_NO_COUNTED_EPI
     if (stores_behind) wait_vmcnt<4 * MT>();
     else
 #endif
       wait_vmcnt<0>();
+#endif
     __builtin_amdgcn_s_barrier();
     if constexpr (M16) {
       using PS = PairSched;
@@ -509,8 +511,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
             aAddr = laneA + (up ? bhi + ((thi / 3) * HS + thi % 3) * ROWB : blo + ((tlo / 3) * HS + tlo % 3) * ROWB);
             bAddr = laneB + (up ? bhi + thi * BN * ROWB : blo + tlo * BN * ROWB);
           }
+#ifndef MAU_CONV_ABL_NOREAD
           if constexpr (R.isA) fa[R.seq % PS::RA] = lds_read128<R.idx * HS * ROWB>(aAddr);
           else fb[R.seq % PS::RB] = lds_read128<R.idx * 16 * ROWB>(bAddr);
+#endif
         };
         static_for<0, kPairSched.lo[0]>([&](auto kc) { issue_read(kc); });
         static_for<0, PS::NM>([&](auto Mc) {
@@ -526,7 +530,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
           mfma32k<F16>(fa[as], fb[bs], acc16[y][n]);
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (M == PS::B1) {                              // stage B's buffer: every wave's DMAs have landed
+#ifndef MAU_CONV_ABL_NOWAIT          // (timing-only: how much of the kernel is WAITING for the DMAs, as opposed to issuing them)
             wait_vmcnt<0>();
+#endif
             __builtin_amdgcn_s_barrier();
           }
           if constexpr (M == PS::B2) {                              // stage A's buffer: everyone is done reading it
@@ -537,17 +543,19 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
             static_for<kPairSched.lo[M], kPairSched.lo[M + 1]>([&](auto kc) { issue_read(kc); });
             __builtin_amdgcn_sched_barrier(0);
           }
-          if constexpr (M < 128 && M % 14 == 10 && M / 14 < PER_WAVE) {
+          if constexpr (M < 128 && M % 14 == 10 && M / 14 < PER_WAVE && !ABL_NODMA) {
             MAU_ISSUE_SLOT(M / 14, stage ^ 1, chunk + 1);
             __builtin_amdgcn_sched_barrier(0);
           }
-          if constexpr (M >= 160 && (M - 160) % 14 == 10 && (M - 160) / 14 < PER_WAVE) {
+          if constexpr (M >= 160 && (M - 160) % 14 == 10 && (M - 160) / 14 < PER_WAVE && !ABL_NODMA) {
             MAU_ISSUE_SLOT((M - 160) / 14, stage, fchunkB);
             __builtin_amdgcn_sched_barrier(0);
           }
         });
         if (moreB) {
+#ifndef MAU_CONV_ABL_NOWAIT
           wait_vmcnt<0>();
+#endif
           __builtin_amdgcn_s_barrier();
         }
       }
@@ -630,88 +638,157 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
     const unsigned rbase = stg + (lane >> 3) * 128 + (lane & 7) * 16;   // read: pixel pass*8 + lane/8, 16-byte vector lane%8
     const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
     if constexpr (M16) {
-      // lane (q = lane / 16, c = lane % 16): pixels x = 4q + r of row y, channel column c of tile n; the packed rows put
-      // channels 32 (n & 1) + 2c + (n >> 1) there, so tiles (n, n + 2) of a lane are an adjacent channel pair
+#ifdef MAU_CONV_ABL_NOEPI            // timing-only: the accumulators are consumed, nothing is staged, counted or stored
+      float t = 0.f;
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) t += acc16[a][b][0] + acc16[a][b][1] + acc16[a][b][2] + acc16[a][b][3];
+      if (t == 1234.5f) yg[lane] = 1;
+#else
+      // lane (q = lane / 16, c = lane % 16): pixels x = 4q + r of row y, channel column c of tile t; the packed rows put
+      // channel 32 (t & 1) + 2c + (t >> 1) there, so tiles (t, t + 2) of a lane are an adjacent channel pair
       const int q4 = (lane >> 4) * 4, c16 = lane & 15;
-      const int cb = cur.co0 + wn * 64 + 2 * c16;               // + 32 n + e
+      const int cb = cur.co0 + wn * 64 + 2 * c16;               // + 32 (t & 1) + (t >> 1)
       const unsigned wb16 = stg + q4 * 128 + c16 * 4;
-      float bv[2][2], s4[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, q4s[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, psc[2][2] = {}, psh[2][2] = {};
+      // Everything per value is PACKED fp32 math on the register pairs the accumulator tiles already are -- (r = 0, 1) and
+      // (r = 2, 3) of one tile: bias and the two statistics cost 6 v_pk_* per tile row instead of 12 scalar operations, and
+      // interior tiles (FULL, the common case) carry no masks.  (One body with the run-time `full` inside made every value a
+      // select: 379 v_cndmask + 224 v_mov per item on top of the arithmetic -- more VALU issue than the item's 576 MFMAs'
+      // shadows hide at level 0, where the epilogue comes every four stages.)
+      float bb[4];
+      f32x2 pscv[4], pshv[4], s2[4], q2[4];
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int ch = cb + 32 * n + e;
-          bv[n][e] = (p.bias != nullptr && ch < p.Cout) ? p.bias[ch] : 0.f;
-          if (EPI == EPI_POST) {
-            psc[n][e] = ch < p.Cout ? p.post_scale[ch] : 0.f;
-            psh[n][e] = ch < p.Cout ? p.post_shift[ch] : 0.f;
-          }
-        }
-      const int xrem = p.W - cur.tx0 - q4;                       // pixel x = q4 + r is inside the image iff r < xrem
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const int ybase = cur.ty0 + wm * 8 + mt * 2;
-        static_for<0, 2>([&](auto yc) {
-          constexpr int yy = decltype(yc)::value;
-          const bool yok = full || ybase + yy < p.H;
-          static_for<0, 2>([&](auto nc) {
-            constexpr int n = decltype(nc)::value;
-            static_for<0, 4>([&](auto rc) {
-              constexpr int r = decltype(rc)::value;
-              float v0 = acc16[mt * 2 + yy][n][r], v1 = acc16[mt * 2 + yy][n + 2][r];
-              if (p.bias != nullptr) {
-                v0 += bv[n][0];
-                v1 += bv[n][1];
-              }
-              if (EPI == EPI_POST) {
-                v0 = fmaxf(fmaf(v0, psc[n][0], psh[n][0]), 0.f);
-                v1 = fmaxf(fmaf(v1, psc[n][1], psh[n][1]), 0.f);
-              }
-              if (EPI == EPI_STATS && (full || (yok && r < xrem))) {
-                s4[n][0] += v0;
-                s4[n][1] += v1;
-                q4s[n][0] = fmaf(v0, v0, q4s[n][0]);
-                q4s[n][1] = fmaf(v1, v1, q4s[n][1]);
-              }
-              const f32x2 v = {v0, v1};
-              lds_write_b32<(yy * 16 + r) * 128 + 64 * n>(wb16, pack_lp2<F16>(v));
-            });
-          });
-        });
-        u32x4 o0 = lds_read_u128<0 * 1024>(rbase), o1 = lds_read_u128<1 * 1024>(rbase);
-        u32x4 o2 = lds_read_u128<2 * 1024>(rbase), o3 = lds_read_u128<3 * 1024>(rbase);
-        lds_land(o0, o1, o2, o3);
-        if (cv < p.ldy) {
-          const u32x4 ov[4] = {o0, o1, o2, o3};
-#pragma unroll
-          for (int pass = 0; pass < 4; ++pass) {
-            const int prow = pass * 8 + (lane >> 3);
-            const int gy = ybase + (prow >> 4), gx = cur.tx0 + (prow & 15);
-            if (full || (gy < p.H && gx < p.W))
-              __builtin_nontemporal_store(ov[pass], reinterpret_cast<u32x4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv));
-          }
+      for (int t = 0; t < 4; ++t) {
+        const int ch = cb + 32 * (t & 1) + (t >> 1);
+        const float bch = (p.bias != nullptr && ch < p.Cout) ? p.bias[ch] : 0.f;
+        bb[t] = bch;
+        s2[t] = f32x2{0.f, 0.f};
+        q2[t] = f32x2{0.f, 0.f};
+        if (EPI == EPI_POST) {
+          const float sc = ch < p.Cout ? p.post_scale[ch] : 0.f, sh = ch < p.Cout ? p.post_shift[ch] : 0.f;
+          pscv[t] = f32x2{sc, sc};
+          pshv[t] = f32x2{sh, sh};
         }
       }
-      if (EPI == EPI_STATS) {
-        float* srow = p.slab + ((size_t)cur.pixTile * WM + wm) * 2 * p.CoutPad + cb;
+      const int xrem = p.W - cur.tx0 - q4;                       // pixel x = q4 + r is inside the image iff r < xrem
+      // The four tile-row groups (mt) of a wave go through ONE 4 KB staging image; DS operations of a wave execute in order, so
+      // group mt's writes may follow group mt - 1's reads without a wait -- only the global stores need the data those reads
+      // return.  The groups are therefore software-pipelined: convert + write(mt), THEN wait for read(mt - 1) (16 writes were issued
+      // behind it: "at most 15 LDS operations outstanding" = it has landed), store(mt - 1), read(mt).  The LDS round trip of a group
+      // hides behind the next group's arithmetic; with everything waited in place each item paid four of them with all eight waves of
+      // the workgroup -- and so the MFMA pipes -- idle.
+      // Output addresses: (uniform 64-bit tile base) + (per-lane 32-bit offset, constant over the kernel) -- the compiler keeps the
+      // base in SGPRs (global_store saddr form) instead of 7 VALU instructions of 64-bit arithmetic per store.
+      const unsigned lane_off = (unsigned)(((lane >> 3) * p.ldy + (lane & 7) * 8) * 2);
+      unsigned char* const ybytes = reinterpret_cast<unsigned char*>(yg);
+      auto rows16 = [&](auto fullc, auto biasc) {
+        constexpr bool FULL = decltype(fullc)::value, BIAS = decltype(biasc)::value;
+        u32x4 o[2][4];
+        auto store_group = [&](int mt, const u32x4 (&ov)[4]) {
+#ifdef MAU_CONV_ABL_NOSTORE
+          if (ov[0][0] + ov[1][1] + ov[2][2] + ov[3][3] == 0x12345678u) yg[lane] = 1;
+#else
+          const int ybase = cur.ty0 + wm * 8 + mt * 2;
+          if (cv < p.ldy) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            s4[n][e] += __shfl_xor(s4[n][e], 16);
-            s4[n][e] += __shfl_xor(s4[n][e], 32);
-            q4s[n][e] += __shfl_xor(q4s[n][e], 16);
-            q4s[n][e] += __shfl_xor(q4s[n][e], 32);
+            for (int pass = 0; pass < 4; ++pass) {
+              const int gyu = ybase + (pass >> 1), gxu = cur.tx0 + (pass & 1) * 8;        // (uniform part of the pixel)
+              const size_t uni = (((size_t)(cur.n * p.H + gyu) * p.W + gxu) * p.ldy + cur.co0 + wn * 64) * 2;
+              if (FULL || (gyu < p.H && gxu + (lane >> 3) < p.W))
+                __builtin_nontemporal_store(ov[pass], reinterpret_cast<u32x4*>(ybytes + uni + lane_off));
+            }
           }
+#endif
+        };
+        static_for<0, 4>([&](auto mc) {
+          constexpr int mt = decltype(mc)::value;
+          const int ybase = cur.ty0 + wm * 8 + mt * 2;
+          static_for<0, 2>([&](auto yc) {
+            constexpr int yy = decltype(yc)::value;
+            const bool yok = FULL || ybase + yy < p.H;
+            f32x2 lo[4], hi[4];
+            static_for<0, 4>([&](auto tc) {
+              constexpr int t = decltype(tc)::value;
+              const f32x4v v = acc16[mt * 2 + yy][t];
+              lo[t] = f32x2{v[0], v[1]};
+              hi[t] = f32x2{v[2], v[3]};
+              if (BIAS) {
+                lo[t] += bb[t];
+                hi[t] += bb[t];
+              }
+              if (EPI == EPI_POST) {
+                lo[t] = __builtin_elementwise_max(__builtin_elementwise_fma(lo[t], pscv[t], pshv[t]), f32x2{0.f, 0.f});
+                hi[t] = __builtin_elementwise_max(__builtin_elementwise_fma(hi[t], pscv[t], pshv[t]), f32x2{0.f, 0.f});
+              }
+#ifndef MAU_CONV_ABL_NOSTATS
+              if (EPI == EPI_STATS) {
+                f32x2 ml = lo[t], mh = hi[t];
+                if (!FULL) {
+                  ml = f32x2{yok && 0 < xrem ? ml[0] : 0.f, yok && 1 < xrem ? ml[1] : 0.f};
+                  mh = f32x2{yok && 2 < xrem ? mh[0] : 0.f, yok && 3 < xrem ? mh[1] : 0.f};
+                }
+                s2[t] += ml;
+                s2[t] += mh;
+                q2[t] = __builtin_elementwise_fma(ml, ml, q2[t]);
+                q2[t] = __builtin_elementwise_fma(mh, mh, q2[t]);
+              }
+#endif
+            });
+            static_for<0, 2>([&](auto nc) {
+              constexpr int n = decltype(nc)::value;
+              lds_write_b32<(yy * 16 + 0) * 128 + 64 * n>(wb16, pack_lp2<F16>(f32x2{lo[n][0], lo[n + 2][0]}));
+              lds_write_b32<(yy * 16 + 1) * 128 + 64 * n>(wb16, pack_lp2<F16>(f32x2{lo[n][1], lo[n + 2][1]}));
+              lds_write_b32<(yy * 16 + 2) * 128 + 64 * n>(wb16, pack_lp2<F16>(f32x2{hi[n][0], hi[n + 2][0]}));
+              lds_write_b32<(yy * 16 + 3) * 128 + 64 * n>(wb16, pack_lp2<F16>(f32x2{hi[n][1], hi[n + 2][1]}));
+            });
+            // (pin the running sums here: the stores are basic-block boundaries, and LLVM's sinking pass otherwise moves the whole
+            //  statistics chain behind the last of them -- all 128 biased values stay live, ~90 registers spill)
+            if (EPI == EPI_STATS)
+              asm volatile("" : "+v"(s2[0]), "+v"(s2[1]), "+v"(s2[2]), "+v"(s2[3]), "+v"(q2[0]), "+v"(q2[1]), "+v"(q2[2]), "+v"(q2[3]));
+          });
+          if constexpr (mt > 0) {
+            lds_land_behind16(o[(mt - 1) & 1][0], o[(mt - 1) & 1][1], o[(mt - 1) & 1][2], o[(mt - 1) & 1][3]);
+            store_group(mt - 1, o[(mt - 1) & 1]);
+          }
+          o[mt & 1][0] = lds_read_u128<0 * 1024>(rbase);
+          o[mt & 1][1] = lds_read_u128<1 * 1024>(rbase);
+          o[mt & 1][2] = lds_read_u128<2 * 1024>(rbase);
+          o[mt & 1][3] = lds_read_u128<3 * 1024>(rbase);
+        });
+        lds_land(o[1][0], o[1][1], o[1][2], o[1][3]);
+        store_group(3, o[1]);
+      };
+      if (p.bias != nullptr) {                         // (workgroup-uniform; the data gradient has no bias to add)
+        if (full) rows16(std::true_type{}, std::true_type{});
+        else rows16(std::false_type{}, std::true_type{});
+      } else {
+        if (full) rows16(std::true_type{}, std::false_type{});
+        else rows16(std::false_type{}, std::false_type{});
+      }
+      if (EPI == EPI_STATS) {
+        // a lane's pair sums -> the channel's sum over the wave's 128 pixels: the lanes q = 0..3 of a column c hold the rest
+        float* srow = p.slab + ((size_t)cur.pixTile * WM + wm) * 2 * p.CoutPad + cb;
+        float st[4], qt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          st[t] = s2[t][0] + s2[t][1];
+          qt[t] = q2[t][0] + q2[t][1];
+          st[t] += __shfl_xor(st[t], 16);
+          st[t] += __shfl_xor(st[t], 32);
+          qt[t] += __shfl_xor(qt[t], 16);
+          qt[t] += __shfl_xor(qt[t], 32);
+        }
         if (lane < 16) {
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
-            const f32x2 sv = {s4[n][0], s4[n][1]}, qv = {q4s[n][0], q4s[n][1]};
+            const f32x2 sv = {st[n], st[n + 2]}, qv = {qt[n], qt[n + 2]};
             *reinterpret_cast<f32x2*>(srow + 32 * n) = sv;
             *reinterpret_cast<f32x2*>(srow + 32 * n + p.CoutPad) = qv;
           }
         }
       }
+#endif   // MAU_CONV_ABL_NOEPI
     } else {
     unsigned wbase[4];                                 // write: row rowbase[g] + k, channel pair 2*i32 (one dword)
 #pragma unroll

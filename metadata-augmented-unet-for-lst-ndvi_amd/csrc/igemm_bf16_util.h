@@ -66,6 +66,11 @@ __device__ __forceinline__ u32x4 lds_read_u128(unsigned addr) {
 __device__ __forceinline__ void lds_land(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+// the reads that returned a..d were followed by (at least) 16 more DS operations of this wave: DS operations complete in order, so
+// "at most 15 outstanding" means the reads have landed (scalar loads share the counter but only ever make the wait longer)
+__device__ __forceinline__ void lds_land_behind16(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {

@@ -864,11 +864,13 @@ def test_fused_adamw_matches_torch_and_keeps_the_packs_fresh(mau, prec):
         opts.append(torch.optim.AdamW(net.parameters(), lr=2e-3, weight_decay=1e-2, fused=True) if kind == "torch"
                     else mau.AdamW(net.parameters(), lr=2e-3, weight_decay=1e-2))
     for step, (x, ts, md, tgt) in enumerate(batches):
+        losses = []
         for net, opt in zip(nets, opts):
             loss = mau.compute_loss_mse(net(x, ts, md), tgt)["total"]
             loss.backward()
             opt.step()
             opt.zero_grad()
+            losses.append(float(loss))
         # the packs written by the fused optimizer == a re-pack from the updated master weights
         net = nets[1].eval()
         with torch.no_grad():
@@ -877,19 +879,26 @@ def test_fused_adamw_matches_torch_and_keeps_the_packs_fresh(mau, prec):
             b = net(x, ts, md)
         net.train()
         assert torch.equal(a, b), step
+        # the two trainings stay together: same loss at every step (the first one bitwise: identical weights and kernels)
+        assert losses[0] == losses[1] if step == 0 else abs(losses[0] - losses[1]) <= (2e-3 if prec == "fp32" else 1e-2) * abs(losses[0]), (step, losses)
         if step == 0:                                        # one step from identical state: tight
             for (k, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
                 assert float((p - q).abs().max()) <= 1e-6 + 1e-5 * float(p.abs().max()), k
-    for (k, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
-        # (four Adam steps amplify last-bit differences -- m / sqrt(v) of ~0 gradients, bf16 activations downstream: 7e-3 measured on the
-        #  metadata MLP in bf16; the one-step check above is the tight one)
-        assert rel_l2(q.detach().cpu(), p.detach().cpu()) < 3e-2, k
+    # Later steps are judged by the losses above, not per parameter: Adam's update is lr * m / sqrt(v) -- of size lr whatever the
+    # gradient's size -- so a last-bit difference in a ~0 gradient (BatchNorm biases start at 0; bf16 activations downstream of a
+    # weight that rounded the other way) moves a parameter by up to 2 lr per step: 7e-2 relative measured on conv0_0.bn1.bias after
+    # four bf16 steps with BOTH optimizers correct.  In fp32 the weights that start away from zero still agree closely:
+    if prec == "fp32":
+        for (k, p), (_, q) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+            if k.endswith("weight") and p.dim() > 1:
+                assert rel_l2(q.detach().cpu(), p.detach().cpu()) < 1e-2, k
     w = nets[1].model.conv2_0.conv1.weight
     assert w.grad is None and w._mau_grad_slot is not None
     # state_dict interchange
     sd_t, sd_m = opts[0].state_dict(), opts[1].state_dict()
-    assert sd_t["state"].keys() == sd_m["state"].keys() and set(sd_m["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
-    assert float(sd_m["state"][0]["step"]) == 4.0
+    k0 = next(iter(sd_m["state"]))                           # (parameters that never saw a gradient -- the unused encoders -- have no state)
+    assert sd_t["state"].keys() == sd_m["state"].keys() and set(sd_m["state"][k0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sd_m["state"][k0]["step"]) == 4.0
     fresh = mau.AdamW(nets[0].parameters(), lr=2e-3, weight_decay=1e-2)
     fresh.load_state_dict(sd_t)
     torch.optim.AdamW(nets[1].parameters(), lr=2e-3, weight_decay=1e-2, fused=True).load_state_dict(sd_m)
