@@ -10,6 +10,8 @@ fuse_embeddings :248-259, head :284-292), src/utils/losses.py:27-39.
 """
 from __future__ import annotations
 
+import dataclasses
+
 import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -491,7 +493,10 @@ class ConvBNReLU(torch.autograd.Function):
                 out = head_of(a)
             elif st.up_to is not None:
                 up = up_of(a)
-        ctx.st = st
+        # (the context must not hold the output: st.out_view IS the returned activation, and node -> ctx -> st -> out_view -> grad_fn
+        #  -> node is a reference cycle that only Python's cycle collector frees -- a whole step's graph, its AccumulateGrad nodes
+        #  included, then outlives the step; a hipGraph capture that meets those stale nodes dies in hipStreamEndCapture)
+        ctx.st = st if st.out_view is None else dataclasses.replace(st, out_view=None)
         ctx.E = E
         ctx.C1 = C1
         ctx.wd = wd                           # data-gradient pack of THIS forward's weights

@@ -107,6 +107,18 @@ class VGGBlock(nn.Module):
 
 
 _SIDE_STREAMS = {}
+_OVERLAP_OFF = [0]          # > 0: inside train_graph.GraphedTrainStep (its warm-up steps and the capture run on ONE stream)
+
+
+class lstm_overlap_disabled:
+    """Context: the TemporalEncoder stays on the current stream (A/B timing, single-stream debugging)."""
+
+    def __enter__(self):
+        _OVERLAP_OFF[0] += 1
+
+    def __exit__(self, *exc):
+        _OVERLAP_OFF[0] -= 1
+        return False
 
 
 def _overlap_lstm(t: torch.Tensor, training: bool) -> bool:
@@ -114,10 +126,12 @@ def _overlap_lstm(t: torch.Tensor, training: bool) -> bool:
     ~0.9 ms backward at the reference's 828 steps: in training it runs on a side stream, beside the first encoder blocks
     (forward) and -- autograd replays a node on its forward stream -- beside the encoder's backward (also under a process
     group: dist.GradSync makes a bucket's launching stream wait for every stream that produced one of its gradients).
-    Not in eval (hipGraph sessions, latency) and not inside a captured train step (train_graph.GraphedTrainStep)."""
-    if not (training and t.is_cuda) or os.environ.get("MAU_OVERLAP_LSTM", "1") == "0":
+    Not in eval (hipGraph sessions, latency)."""
+    if not (training and t.is_cuda) or _OVERLAP_OFF[0] > 0 or os.environ.get("MAU_OVERLAP_LSTM", "1") == "0":
         return False
-    return not torch.cuda.is_current_stream_capturing()
+    # inside a captured train step the side stream forks from / joins the capturing stream (wait_stream both ways): the
+    # overlap becomes two branches of the hipGraph (MAU_OVERLAP_LSTM_GRAPH=0: one branch)
+    return not torch.cuda.is_current_stream_capturing() or os.environ.get("MAU_OVERLAP_LSTM_GRAPH", "1") != "0"
 
 
 class TemporalEncoder(nn.Module):

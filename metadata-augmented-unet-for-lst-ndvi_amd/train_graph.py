@@ -20,6 +20,7 @@ change between calls.  A failed capture raises -- it is never retried or silentl
 """
 from __future__ import annotations
 
+import gc
 from typing import Callable, Optional, Sequence
 
 import torch
@@ -81,6 +82,10 @@ class GraphedTrainStep:
         else:
             self._in = list(batch)
         self.optimizer.zero_grad(set_to_none=True)        # the captured backward ASSIGNS the gradients (static buffers of the graph)
+        # An autograd graph of an earlier step that is still alive (a reference cycle in user code, a kept loss) keeps its
+        # AccumulateGrad nodes, bound to the stream they were created on; the captured backward would re-use them and make the engine
+        # synchronise with that stream -- on ROCm 7.2 the capture then dies in hipStreamEndCapture instead of raising.
+        gc.collect()
         # Who re-packs the convolution weights?  torch's optimizers: the captured forward starts with the (captured) multi-tensor
         # re-pack.  optim.AdamW writes the packs together with the update: the captured step then contains NO separate pack -- the
         # forward of replay k reads what the optimizer of replay k - 1 (or of the last warm-up step) wrote.

@@ -54,7 +54,8 @@ for name, cin, cout, h in layers:
     minb = (F_.pad8(cin) + F_.pad8(cout)) * N * H * W * 2 + 9 * cin * cout * 2
     records.append({"layer": name, "Cin": cin, "Cout": cout, "H": h, "B": B, "gflop": fl / 1e9, "min_hbm_bytes": minb,
                     "variant": ("BN128" if ((cout + 63) // 64 * 64) % 128 == 0 else "BN64") + f"/tiles{tiles}",
-                    **{k: {"us": t * 1e6, "tflops": fl / t / 1e12, "tbps_min_bytes": minb / t / 1e12} for k, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw))},
+                    **{k: {"us": t * 1e6, "tflops": fl / t / 1e12, "mfma_frac": fl / t / 2.5e15, "tbps_min_bytes": minb / t / 1e12, "hbm_frac": minb / t / 8e12}
+                       for k, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw))},
                     "wgrad_splits": ns})
 print(f"TOTAL fwd {tot['fwd']*1e3:.2f} ms ({totf/tot['fwd']/1e12:.0f} TF/s)  dgrad {tot['dgrad']*1e3:.2f} ms  wgrad {tot['wgrad']*1e3:.2f} ms ({totf/tot['wgrad']/1e12:.0f} TF/s)")
 
@@ -67,5 +68,7 @@ if os.environ.get("OUT"):
                "north_star_layer_conv0_0_DoubleConv": {"fwd_us": sum(r["fwd"]["us"] for r in d00), "gflop": sum(r["gflop"] for r in d00),
                                                       "min_hbm_bytes": sum(r["min_hbm_bytes"] for r in d00),
                                                       "fwd_tflops": sum(r["gflop"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e3,
-                                                      "fwd_tbps_min_bytes": sum(r["min_hbm_bytes"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e-6},
+                                                      "fwd_tbps_min_bytes": sum(r["min_hbm_bytes"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e-6,
+                                                      "fwd_hbm_frac": sum(r["min_hbm_bytes"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e-6 / 8.0,
+                                                      "fwd_hbm_frac_of_achievable": sum(r["min_hbm_bytes"] for r in d00) / sum(r["fwd"]["us"] for r in d00) * 1e-6 / 6.3},
                "totals_ms": {k: v * 1e3 for k, v in tot.items()}, "layers": records}, open(os.environ["OUT"], "w"), indent=1)

@@ -693,11 +693,11 @@ def test_train_cli_writes_reference_checkpoint_and_reloads(mau, tmp_path):
     assert checkpoint.run_inference(loaded, x.cpu(), md.cpu(), ts.cpu()).shape == (1, 2, 250, 250)
 
 
-def _train_n_steps(mau, model_type, prec, steps, graphed, seed=60, T=24, fused_opt=False):
+def _train_n_steps(mau, model_type, prec, steps, graphed, seed=60, T=24, fused_opt=False, base_filters=16):
     """``steps`` training steps on a sequence of different batches; returns (losses, parameters, BN buffers)."""
     flags = {} if model_type == "unet++" else dict(temporal_embeddings=True, metadata_embeddings=True)
     torch.manual_seed(seed)
-    net = mau.UrbanPredictor(model_type, 6, T, 16, 4, 16, 24, 2, base_filters=16, **flags).cuda().set_precision(prec).train()
+    net = mau.UrbanPredictor(model_type, 6, T, 16, 4, 16, 24, 2, base_filters=base_filters, **flags).cuda().set_precision(prec).train()
     opt = (mau.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-3) if fused_opt
            else torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-3, fused=True, capturable=True))
     crit = mau.compute_loss_mse_gradient
@@ -735,6 +735,20 @@ def test_graphed_train_step_matches_eager(mau, model_type, prec, fused_opt):
     for la, lb in zip(a[0], b[0]):
         assert torch.equal(la, lb), (a[0], b[0])
     assert float(a[0][0]) != float(a[0][5])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+    assert torch.equal(a[2], b[2])
+
+
+def test_graphed_train_step_unetpp_row_buffers(mau):
+    """U-Net++ at the production width (base_filters=64: the nodes of a row live in row buffers, functional.RowPrefix) through
+    GraphedTrainStep, against the eager steps.  Regression: the autograd context of a block used to hold the row-buffer view it returns
+    (a reference cycle), the previous step's graph and its AccumulateGrad nodes survived into the capture, and hipStreamEndCapture
+    crashed the process -- the narrow models of the test above never take the row-buffer path."""
+    a = _train_n_steps(mau, "unet++", "bf16", 5, graphed=False, fused_opt=True, base_filters=64)
+    b = _train_n_steps(mau, "unet++", "bf16", 5, graphed=True, fused_opt=True, base_filters=64)
+    for la, lb in zip(a[0], b[0]):
+        assert torch.equal(la, lb), (a[0], b[0])
     for k in a[1]:
         assert torch.equal(a[1][k], b[1][k]), k
     assert torch.equal(a[2], b[2])
