@@ -360,7 +360,7 @@ def main():
         wach = wg["total_flop"] / (wg["total_ms"] * 1e-3) / 1e12
         wrec = rec.get("wgrad", {})
         wflop = wg["total_flop"] / wg["launches"]
-        roofline["wgrad"] = {"kernel": "wgrad_bf16_kernel", "achieved": round(wach, 2), "frac": round(wach / peak, 4),
+        roofline["wgrad"] = {"kernel": "wgrad16_kernel (+ wgrad_bf16_kernel on small images)", "achieved": round(wach, 2), "frac": round(wach / peak, 4),
                              "launches": wg["launches"], "avg_launch_ms": round(wg["total_ms"] / wg["launches"], 4),
                              "traffic": wrec.get("hbm_bytes_per_launch_pmc"), "algorithmic_bytes": round(timer.wbytes / wg["launches"]),
                              "traffic_ratio": round(wrec["hbm_bytes_per_launch_pmc"] / (timer.wbytes / wg["launches"]), 3) if wrec.get("hbm_bytes_per_launch_pmc") else None,
