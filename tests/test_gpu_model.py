@@ -754,6 +754,32 @@ def test_graphed_train_step_unetpp_row_buffers(mau):
     assert torch.equal(a[2], b[2])
 
 
+def test_inplace_op_on_a_row_buffer_raises_in_backward(mau, monkeypatch):
+    """U-Net++ row buffers are written by raw kernels through ``BNState.out_view`` and read through views; a torch in-place op on
+    the buffer would make autograd rebuild the views' history from a base that has none.  It must not pass silently: the slots are
+    saved tensors of their consumers, whose version check turns the bump into an error in backward."""
+    from mau_amd import model as M
+    seen = []
+    orig = M.UrbanPredictor_unetpp._node
+
+    def spy(self, block, skips, below, emb, out_view=None, **kw):
+        if out_view is not None:
+            seen.append(out_view)
+        return orig(self, block, skips, below, emb, out_view, **kw)
+
+    monkeypatch.setattr(M.UrbanPredictor_unetpp, "_node", spy)
+    torch.manual_seed(5)
+    net = mau.UrbanPredictor("unet++", 6, 10, 16, 4, 16, 24, 2, base_filters=64).cuda().set_precision("bf16").train()
+    x, ts, md = torch.randn(2, 6, 32, 32).cuda(), torch.randn(2, 10).cuda(), torch.randn(2, 4).cuda()
+    out = net(x, ts, md)
+    assert seen and seen[0]._base is not None            # the slots are views of one buffer per row
+    seen[0]._base.add_(0)                                # any in-place torch op on the buffer
+    # (autograd's own words: either the saved-tensor version check, or "is a view and its base ... has been modified inplace.
+    #  This view was created inside a custom Function ... This behavior is forbidden.")
+    with pytest.raises(RuntimeError, match="modified by an inplace operation|has been modified inplace"):
+        out.float().sum().backward()
+
+
 def test_single_launch_reductions_and_multi_pack_are_bit_identical(mau, monkeypatch):
     """Launch-tail fusions of round 3 against the forms they replace, same arithmetic in the same order: the single-launch slab
     reductions (ticket: the last workgroup runs the second level; functional._FUSED_REDUCE) vs two launches, and the one-launch
