@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--no-sync-bn", action="store_true", help="per-GPU BatchNorm statistics (reference semantics per device)")
     ap.add_argument("--seq-len", type=int, default=10, help="length of the temperature series (reference data: 828, conf/config.yaml:20)")
     ap.add_argument("--temporal-embeddings", action="store_true", help="U-Net with the LSTM TemporalEncoder on the path (always on for unet++)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal on ONE GPU: take the data-parallel code path (SyncBN all-reduces, "
+                                                              "bucketed gradient all-reduce from autograd hooks, eager launches) under a 1-rank RCCL group")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; default: the "
                          "figure committed under profiles/ for the same workload (profiles/r2/pmc_summary.json)")
@@ -219,7 +221,11 @@ def main():
     opt = (torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-3, fused=True) if args.torch_adamw
            else mau_amd.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-3))
     sync = None
-    if world > 1:
+    if args.force_dist and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    if world > 1 or args.force_dist:
         if not args.no_sync_bn:
             net.set_sync_bn(dist.group.WORLD)
         sync = GradSync(net, dist.group.WORLD)
@@ -230,9 +236,11 @@ def main():
             net(x, ts, md)
 
     graphed = None
-    if not args.infer and world == 1 and not args.no_graph:
+    # data parallel: eager by default (the collectives are launched from autograd hooks); MAU_DP_GRAPH=1 captures them too
+    dp_graph = sync is not None and os.environ.get("MAU_DP_GRAPH", "0") == "1"
+    if not args.infer and not args.no_graph and ((world == 1 and sync is None) or dp_graph):
         criterion = lambda o, t: mau_amd.compute_loss_mse(o, t)          # noqa: E731  (src/train.py:218-219)
-        graphed = mau_amd.GraphedTrainStep(net, opt, criterion, warmup=min(3, max(1, args.warmup)), copy_inputs=False)
+        graphed = mau_amd.GraphedTrainStep(net, opt, criterion, warmup=min(3, max(1, args.warmup)), copy_inputs=False, grad_sync=sync)
 
     def step(i):
         if args.infer:
@@ -294,7 +302,11 @@ def main():
         for i in range(args.steps):
             out = net(x, ts, md)
             loss = mau_amd.compute_loss_mse(out, tgt)["total"]
+            if sync is not None:
+                sync.begin()
             loss.backward()
+            if sync is not None:
+                sync.finish()
             opt.step()
             opt.zero_grad()
         torch.cuda.synchronize()
@@ -381,7 +393,7 @@ def main():
         "config": {"workload": (f"metadata-{args.model_type} base_filters=64, {B}x{args.channels}x{S}x{S} tiles + {args.meta}-dim metadata per GPU, "
                                 + (f"temperature series of {args.seq_len} months, " if (args.seq_len != 10 or args.temporal_embeddings) else "")
                                 + ("eval-mode forward only (inference)" if args.infer else "fwd+MSE+bwd+AdamW (src/train.py:243-256)")),
-                   "global_batch": B * world, "parallelism": f"dp{world}",
+                   "global_batch": B * world, "parallelism": f"dp{world}" + (" (data-parallel path forced under a 1-rank RCCL group)" if args.force_dist and world == 1 else ""),
                    "sync_bn": bool(world > 1 and not args.no_sync_bn),
                    "launch": "hipGraph replay of the captured step" if graphed is not None else "eager (kernel by kernel)"},
         "rccl_ranks": rccl_ranks,

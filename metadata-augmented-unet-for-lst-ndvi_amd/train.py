@@ -132,7 +132,9 @@ def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study
     clip = 5.0 if cfg.gradient_clipping > 0 else 0.0                                            # src/train.py:253-254
     # one GPU: the step (forward, criterion, backward, clip, optimizer) is captured once and replayed (static shapes);
     # data parallel: eager, the RCCL collectives are launched from autograd hooks while backward still runs
-    gstep = GraphedTrainStep(model, optimizer, criterion, clip_grad_norm=clip) if (graph and sync is None) else None
+    # (MAU_DP_GRAPH=1: the data-parallel step is captured too, collectives included -- train_graph.py)
+    dp_graph = sync is not None and os.environ.get("MAU_DP_GRAPH", "0") == "1"
+    gstep = GraphedTrainStep(model, optimizer, criterion, clip_grad_norm=clip, grad_sync=sync) if (graph and (sync is None or dp_graph)) else None
     best, step, ckpt_path, history = float("inf"), 0, None, []
     for epoch in range(epochs if epochs is not None else cfg.epochs):
         model.train()

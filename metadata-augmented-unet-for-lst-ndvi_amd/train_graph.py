@@ -6,17 +6,20 @@
 
 A train step of the U-Net is ~190 kernel launches of 2 us .. 400 us; launched one by one from Python the
 short ones (weight packs, slab reductions, BatchNorm finalizes, split-K sums) leave the GPU waiting for
-the host.  The C ABI allocates nothing and never synchronises, the optimizer is torch's capturable fused
-AdamW, and every reduction keeps its workspace in torch's caching allocator -- so the whole step is
+the host.  The C ABI allocates nothing and never synchronises, the optimizer (mau_amd.AdamW, or torch's fused
+AdamW made capturable) reads its step count from device memory, and every reduction keeps its workspace in torch's caching allocator -- so the whole step is
 capturable: the first ``warmup`` calls run eagerly (they are ordinary training steps on the batches they
 are given; they also warm the allocator and set the kernels' LDS attributes), the next call captures
 forward, criterion, backward and the optimizer step into a graph and replays it, every later call only
 refreshes the static input buffers and replays.  Results are bit-identical to the eager step
 (``tests/test_gpu_model.py::test_graphed_train_step_matches_eager``).
 
-Not captured (eager instead): data-parallel runs (``dist.GradSync`` overlaps RCCL collectives with
-backward from Python hooks), gradient clipping by norm under a process group, anything whose shapes
-change between calls.  A failed capture raises -- it is never retried or silently replaced.
+Data parallel: with ``grad_sync=dist.GradSync(...)`` the bucketed gradient all-reduces and the model's SyncBN all-reduces are
+captured too (RCCL kernels become graph nodes; torch's ProcessGroupNCCL joins its internal stream to the capture).  Measured on one
+GPU under a 1-rank RCCL group: eager data-parallel step 14.4 ms, captured 13.5 ms, plain captured step 13.0 ms (same box) -- the
+data-parallel path's extra cost is mostly host work that the graph removes.  ``bench.py`` and ``train.run`` keep the data-parallel
+step EAGER unless ``MAU_DP_GRAPH=1``: a capture that goes wrong at N > 1 cannot be rehearsed on the one-GPU boxes this was built on,
+and a hung rank costs the whole measurement.  Not captured: anything whose shapes change between calls.  A failed capture raises -- it is never retried or silently replaced.
 """
 from __future__ import annotations
 
@@ -48,11 +51,12 @@ class GraphedTrainStep:
     tensors (a resident synthetic batch, or buffers the loader fills in place); the default copies every batch in."""
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, criterion: Callable, warmup: int = 3,
-                 clip_grad_norm: float = 0.0, copy_inputs: bool = True):
+                 clip_grad_norm: float = 0.0, copy_inputs: bool = True, grad_sync=None):
         self.model, self.optimizer, self.criterion = model, optimizer, criterion
         self.warmup = max(1, int(warmup))
         self.clip = float(clip_grad_norm)
         self.copy_inputs = copy_inputs
+        self.grad_sync = grad_sync                 # dist.GradSync: its bucketed all-reduces (and the model's SyncBN ones) become graph nodes
         self.calls = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._in: Optional[Sequence[torch.Tensor]] = None
@@ -69,7 +73,11 @@ class GraphedTrainStep:
     def _eager(self, maps, temp_series, metadata, targets):
         outputs = self.model(maps, temp_series, metadata)                      # src/train.py:245
         loss = self._loss_of(outputs, targets)                                 # :247-249
+        if self.grad_sync is not None:
+            self.grad_sync.begin()
         loss.backward()                                                        # :252
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
         if self.clip > 0:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)  # :253-254
         self.optimizer.step()                                                  # :255
@@ -99,7 +107,11 @@ class GraphedTrainStep:
             with torch.cuda.graph(graph):
                 outputs = self.model(self._in[0], self._in[1], self._in[2])
                 loss = self._loss_of(outputs, self._in[3])
+                if self.grad_sync is not None:
+                    self.grad_sync.begin()
                 loss.backward()
+                if self.grad_sync is not None:
+                    self.grad_sync.finish()
                 if self.clip > 0:
                     torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
                 self.optimizer.step()

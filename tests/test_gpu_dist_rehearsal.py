@@ -129,6 +129,33 @@ for synced in (False, True):
         opt.step(); opt.zero_grad()
     torch.cuda.synchronize()
     res[("unet++", synced)] = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if v.is_floating_point()}
+# the data-parallel step as ONE hipGraph (GraphedTrainStep(grad_sync=...): the SyncBN and bucket all-reduces are captured RCCL nodes):
+# five steps, captured at the third, against the same five steps launched eagerly -- bit for bit
+kw3 = dict(model_type="unet", spatial_channels=6, seq_len=10, temporal_dim=8, meta_features=4, meta_dim=8, lstm_dim=12, out_channels=2,
+           base_filters=16, temporal_embeddings=False, metadata_embeddings=True)
+for graphed in (False, True):
+    torch.manual_seed(2)
+    net = mau_amd.UrbanPredictor(**kw3).cuda().set_precision("bf16").train()
+    opt = mau_amd.AdamW(net.parameters(), lr=1e-3)
+    net.set_sync_bn(dist.group.WORLD)
+    sync = GradSync(net, dist.group.WORLD, bucket_bytes=64 << 10)
+    crit = mau_amd.compute_loss_mse
+    gstep = mau_amd.GraphedTrainStep(net, opt, crit, warmup=2, grad_sync=sync) if graphed else None
+    gg = torch.Generator().manual_seed(9)
+    losses = []
+    for step in range(5):
+        xb, mb, tb = torch.randn(4, 6, 32, 32, generator=gg).cuda(), torch.randn(4, 4, generator=gg).cuda(), torch.randn(4, 2, 32, 32, generator=gg).cuda()
+        if graphed:
+            losses.append(float(gstep(xb, ts, mb, tb)))
+        else:
+            loss = crit(net(xb, ts, mb), tb)["total"]
+            sync.begin(); loss.backward(); sync.finish()
+            opt.step(); opt.zero_grad()
+            losses.append(float(loss))
+    torch.cuda.synchronize()
+    if graphed: assert gstep.graph is not None
+    res[("dpgraph", graphed)] = {"losses": torch.tensor(losses), **{k: v.detach().float().cpu() for k, v in net.state_dict().items() if v.is_floating_point()}}
+    sync.remove()
 # the training driver on the data-parallel path (SyncBN + GradSync + eager step + validate() + best-validation checkpoint)
 from mau_amd import train
 from mau_amd.config import CONFIG
@@ -165,6 +192,10 @@ def test_rccl_collectives_one_rank_group(tmp_path):
     num = sum(float(((a[k] - b[k]).double() ** 2).sum()) for k in a)
     den = sum(float((a[k].double() ** 2).sum()) for k in a)
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+    # the captured data-parallel step == the eager data-parallel step
+    a, b = res[("dpgraph", False)], res[("dpgraph", True)]
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
     assert float(res["train_best"]) < float("inf")
 
 
