@@ -259,83 +259,112 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* __restr
   }
 }
 
+// Pixel index -> (image n, pixel q inside the image) for the NCHW fp32 tensors of the head (out, dout): ONE division per thread at
+// its first pixel, then steps of 32 pixels with a conditional wrap (HW >= 32, checked by the entry points).  (A 64-bit division per
+// pixel -- or a `while (q >= HW)` wrap, which the compiler turns into nested loop copies full of v_mov -- cost more than the
+// arithmetic of the pixel.)
+__device__ __forceinline__ void pos_step32(int& n, int& q, int HW) {
+  q += 32;
+  const bool w = q >= HW;
+  q -= w ? HW : 0;
+  n += w ? 1 : 0;
+}
+
 // ---- head: forward with BatchNorm + ReLU applied while the activation is loaded (head_fwd_kernel's mapping and arithmetic) ----
-template <typename T, int MC>
+// EX: Co == MC (no per-term `o < Co` selects).  A workgroup owns `pixb` consecutive pixels, a thread one 8-channel vector of every
+// 32nd pixel, four pixels per iteration (their loads are issued together).  After the 8-lane butterfly every lane of a pixel holds the
+// pixel's Co sums; lane `sub` (0..3) then finishes pixel u = sub of the iteration -- bias, tanh, store -- so that tanhf and the
+// address arithmetic run once per FOUR pixels instead of once per pixel (they are exec-masked scalar code: the wave pays in full).
+template <typename T, int MC, bool EX>
 __global__ __launch_bounds__(256) void head_bn_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ w,
                                                           const float* __restrict__ b, float* __restrict__ out, int tanh0, int HW, int C,
-                                                          int Co, int64_t npix) {
-  const int sub = threadIdx.x & 7;
+                                                          int Co, int64_t npix, int pixb) {
+  const int sub = threadIdx.x & 7, ps = threadIdx.x >> 3;
   float wr[MC][8];
 #pragma unroll
   for (int o = 0; o < MC; ++o)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wr[o][j] = o < Co ? coef(w + o * C, sub * 8 + j, C) : 0.f;
+    for (int j = 0; j < 8; ++j) wr[o][j] = (EX || o < Co) ? coef(w + o * C, sub * 8 + j, C) : 0.f;
   Coef8 k;
   k.load(scale, shift, nullptr, nullptr, sub * 8, C);
-  // four pixels per thread and iteration (their loads are issued together); block-uniform trip count
-  const int64_t stride = (int64_t)gridDim.x * 128;
-  for (int64_t pix0 = (int64_t)blockIdx.x * 128; pix0 < npix; pix0 += stride) {
+  float bo[MC];
+#pragma unroll
+  for (int o = 0; o < MC; ++o) bo[o] = (EX || o < Co) ? b[o] : 0.f;
+  const int64_t p0 = (int64_t)blockIdx.x * pixb;
+  const int64_t p1 = p0 + pixb < npix ? p0 + pixb : npix;
+  int n = (int)((p0 + ps) / HW);
+  int q = (int)((p0 + ps) - (int64_t)n * HW);
+  for (int64_t p = p0 + ps; p - ps < p1; p += 128) {       // (block-uniform trip count: the butterflies below need every lane)
     F8 x[4];
+    int nn[4], qq[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int64_t pix = pix0 + 32 * u + (threadIdx.x >> 3);
+      const int64_t pix = p + 32 * u;
       const int64_t pc = pix < npix ? pix : npix - 1;                      // (clamped: unconditional load)
       x[u] = load8<T>(y + pc * ldy + (sub * 8 < C ? sub * 8 : 0));
+      nn[u] = n;
+      qq[u] = q;
+      pos_step32(n, q, HW);
     }
+    float acc[4][MC];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int64_t pix = pix0 + 32 * u + (threadIdx.x >> 3);
-      const bool live = pix < npix;
-      float acc[MC];
 #pragma unroll
-      for (int o = 0; o < MC; ++o) acc[o] = 0.f;
+      for (int o = 0; o < MC; ++o) acc[u][o] = 0.f;
       if (sub * 8 < C) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float a = round_to<T>(fmaxf(fmaf(x[u].v[j], k.sc[j], k.sh[j]), 0.f));
 #pragma unroll
-          for (int o = 0; o < MC; ++o) acc[o] = fmaf(a, wr[o][j], acc[o]);
+          for (int o = 0; o < MC; ++o) acc[u][o] = fmaf(a, wr[o][j], acc[u][o]);
         }
       }
 #pragma unroll
       for (int o = 0; o < MC; ++o) {
-        acc[o] += __shfl_xor(acc[o], 1);
-        acc[o] += __shfl_xor(acc[o], 2);
-        acc[o] += __shfl_xor(acc[o], 4);
+        acc[u][o] += __shfl_xor(acc[u][o], 1);
+        acc[u][o] += __shfl_xor(acc[u][o], 2);
+        acc[u][o] += __shfl_xor(acc[u][o], 4);
       }
-      if (live && sub < Co) {
-        float r = 0.f;
+    }
+    // lane sub < 4 finishes pixel u = sub
+    const int us = sub & 3;
+    const int nu = us == 0 ? nn[0] : us == 1 ? nn[1] : us == 2 ? nn[2] : nn[3];
+    const int qu = us == 0 ? qq[0] : us == 1 ? qq[1] : us == 2 ? qq[2] : qq[3];
+    const bool live = sub < 4 && p + 32 * us < p1;
 #pragma unroll
-        for (int o = 0; o < MC; ++o)
-          if (o == sub) r = acc[o];
-        r += b[sub];
-        if (tanh0 && sub == 0) r = tanhf(r);
-        const int64_t n = pix / HW, q = pix - n * HW;
-        out[((size_t)n * Co + sub) * HW + q] = r;
+    for (int o = 0; o < MC; ++o) {
+      if (EX || o < Co) {
+        float r = us == 0 ? acc[0][o] : us == 1 ? acc[1][o] : us == 2 ? acc[2][o] : acc[3][o];
+        r += bo[o];
+        if (o == 0 && tanh0) r = tanhf(r);
+        if (live) out[((size_t)nu * Co + o) * HW + qu] = r;
       }
     }
   }
 }
 
 // dz of the head at pixel (n, q): dout * (1 - out^2) on the tanh channel (unconditional loads, clamped channel index)
-template <int MC>
-__device__ __forceinline__ void head_dz(const float* __restrict__ out, const float* __restrict__ dout, int tanh0, int Co, int HW, int64_t n,
+template <int MC, bool EX>
+__device__ __forceinline__ void head_dz(const float* __restrict__ out, const float* __restrict__ dout, int tanh0, int Co, int HW, int n,
                                         int q, float* dz) {
   const size_t base = (size_t)n * Co * HW + q;
   const float t = out[base];
   const float f0 = tanh0 ? fmaf(-t, t, 1.f) : 1.f;
 #pragma unroll
   for (int o = 0; o < MC; ++o) {
-    const float g = dout[base + (size_t)(o < Co ? o : Co - 1) * HW];
-    dz[o] = o < Co ? (o == 0 ? g * f0 : g) : 0.f;
+    const float g = dout[base + (size_t)((EX || o < Co) ? o : Co - 1) * HW];
+    dz[o] = (EX || o < Co) ? (o == 0 ? g * f0 : g) : 0.f;
   }
 }
 
 // ---- head: backward pass 1.  One workgroup = BWD_PIX_PER_BLOCK pixels x all C <= 64 channels: BatchNorm partial sums (slab row
 // as bn_relu_bwd_reduce_kernel) and the head's dW / db partials (slab row as head_bwd_kernel) in one pass over y ----
-template <typename T, int MC>
-__global__ __launch_bounds__(256) void head_bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+#ifndef MAU_HEAD_WAVES
+#define MAU_HEAD_WAVES 3          // 168 registers instead of 170: three waves per SIMD instead of two
+#endif
+template <typename T, int MC, bool EX>
+__global__ __launch_bounds__(256, MAU_HEAD_WAVES) void head_bn_bwd_reduce_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const float* __restrict__ w,
                                                                  const float* __restrict__ out, const float* __restrict__ dout,
@@ -373,7 +402,7 @@ __global__ __launch_bounds__(256) void head_bn_bwd_reduce_kernel(const T* __rest
       float s = 0.f;
 #pragma unroll
       for (int o = 0; o < MC; ++o)
-        if (o < Co) {
+        if (EX || o < Co) {
           s = fmaf(dz[o], wr[o][j], s);
           dwp[o][j] = fmaf(dz[o], a, dwp[o][j]);
         }
@@ -383,43 +412,35 @@ __global__ __launch_bounds__(256) void head_bn_bwd_reduce_kernel(const T* __rest
       s2[j] = fmaf(dzb, (v.v[j] - k.mu[j]) * k.is[j], s2[j]);
     }
   };
-  auto wrap = [&](int64_t& n, int& q) {
-    while (q >= HW) {
-      q -= HW;
-      ++n;
-    }
-  };
   if (c0 < C8) {
-    int64_t n = (p0 + ps) / HW;
-    int q = (int)((p0 + ps) - n * HW);
+    int n = (int)((p0 + ps) / HW);
+    int q = (int)((p0 + ps) - (int64_t)n * HW);
     int64_t p = p0 + ps;
     for (; p + 32 < p1; p += 64) {                       // two pixels per iteration: their loads are issued together (four: slower,
-      int64_t n2 = n;                                    //  the 2 x (dW, db) accumulators leave no room for four vectors in flight)
-      int q2 = q + 32;
-      wrap(n2, q2);
+      int n2 = n, q2 = q;                                //  the 2 x (dW, db) accumulators leave no room for four vectors in flight)
+      pos_step32(n2, q2, HW);
       float dza[MC], dzb2[MC];
       const F8 va = load8<T>(y + p * ldy + c0), vb = load8<T>(y + (p + 32) * ldy + c0);
-      head_dz<MC>(out, dout, tanh0, Co, HW, n, q, dza);
-      head_dz<MC>(out, dout, tanh0, Co, HW, n2, q2, dzb2);
+      head_dz<MC, EX>(out, dout, tanh0, Co, HW, n, q, dza);
+      head_dz<MC, EX>(out, dout, tanh0, Co, HW, n2, q2, dzb2);
       one(va, dza);
       one(vb, dzb2);
       n = n2;
-      q = q2 + 32;
-      wrap(n, q);
+      q = q2;
+      pos_step32(n, q, HW);
     }
     for (; p < p1; p += 32) {
       float dz[MC];
       const F8 v = load8<T>(y + p * ldy + c0);
-      head_dz<MC>(out, dout, tanh0, Co, HW, n, q, dz);
+      head_dz<MC, EX>(out, dout, tanh0, Co, HW, n, q, dz);
       one(v, dz);
-      q += 32;
-      wrap(n, q);
+      pos_step32(n, q, HW);
     }
   }
   // head partials (head_bwd_kernel's LDS join; one 64-channel group)
 #pragma unroll
   for (int o = 0; o < MC; ++o)
-    if (o < Co) {
+    if (EX || o < Co) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) hred[(ps * HEAD_MAX_CO + o) * 65 + cv * 8 + j] = dwp[o][j];
     }
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(256) void head_bn_bwd_reduce_kernel(const T* __rest
 }
 
 // ---- head: backward pass 2: dy of the conv in front of the BatchNorm, da recomputed from dout ----
-template <typename T, int MC>
+template <typename T, int MC, bool EX>
 __global__ __launch_bounds__(256) void head_bn_bwd_apply_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const double* __restrict__ sums,
@@ -467,14 +488,8 @@ __global__ __launch_bounds__(256) void head_bn_bwd_apply_kernel(const T* __restr
     for (int j = 0; j < 8; ++j) wr[o][j] = o < Co ? coef(w + o * C, c0 + j, C) : 0.f;
   const int64_t p0 = (int64_t)blockIdx.x * pixb;
   const int64_t p1 = p0 + pixb < npix ? p0 + pixb : npix;
-  int64_t n = (p0 + ps) / HW;
-  int q = (int)((p0 + ps) - n * HW);
-  auto wrap = [&](int64_t& nn, int& qq) {
-    while (qq >= HW) {
-      qq -= HW;
-      ++nn;
-    }
-  };
+  int n = (int)((p0 + ps) / HW);
+  int q = (int)((p0 + ps) - (int64_t)n * HW);
   auto one = [&](int64_t p, const F8& v, const float* dz) {
     F8 o8;
 #pragma unroll
@@ -482,28 +497,26 @@ __global__ __launch_bounds__(256) void head_bn_bwd_apply_kernel(const T* __restr
       float s = 0.f;
 #pragma unroll
       for (int o = 0; o < MC; ++o)
-        if (o < Co) s = fmaf(dz[o], wr[o][j], s);
+        if (EX || o < Co) s = fmaf(dz[o], wr[o][j], s);
       o8.v[j] = k.dy(j, v.v[j], round_to<T>(s));
     }
     store8<T>(dyo + p * lddy + c0, o8);
   };
   int64_t p = p0 + ps;
   for (; p + 96 < p1; p += 128) {                        // four pixels per iteration: their loads are issued together
-    int64_t nn[4];
-    int qq[4];
+    int nn[4], qq[4];
     F8 v[4];
     float dz[4][MC];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       nn[u] = n;
       qq[u] = q;
-      q += 32;
-      wrap(n, q);
+      pos_step32(n, q, HW);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       v[u] = load8<T>(y + (p + 32 * u) * ldy + c0);
-      head_dz<MC>(out, dout, tanh0, Co, HW, nn[u], qq[u], dz[u]);
+      head_dz<MC, EX>(out, dout, tanh0, Co, HW, nn[u], qq[u], dz[u]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) one(p + 32 * u, v[u], dz[u]);
@@ -511,10 +524,9 @@ __global__ __launch_bounds__(256) void head_bn_bwd_apply_kernel(const T* __restr
   for (; p < p1; p += 32) {
     float dz[MC];
     const F8 v = load8<T>(y + p * ldy + c0);
-    head_dz<MC>(out, dout, tanh0, Co, HW, n, q, dz);
+    head_dz<MC, EX>(out, dout, tanh0, Co, HW, n, q, dz);
     one(p, v, dz);
-    q += 32;
-    wrap(n, q);
+    pos_step32(n, q, HW);
   }
 }
 
@@ -576,15 +588,19 @@ int mau_head_bn_fwd(const void* y, int ldy, const float* scale, const float* shi
   MAU_REQUIRE(Co >= 1 && Co <= HEAD_MAX_CO && C <= mau_head_bn_max_channels(), "head_bn_fwd: out_channels in [1,%d], C <= %d", HEAD_MAX_CO,
               mau_head_bn_max_channels());
   MAU_REQUIRE(ldy % 8 == 0 && ldy >= round_up(C, 8), "head_bn_fwd: bad ld");
+  MAU_REQUIRE(HW >= 32 && (int64_t)N * HW < ((int64_t)1 << 31), "head_bn_fwd: images of at least 32 pixels, fewer than 2^31 pixels in all");
   const int64_t npix = (int64_t)N * HW;
-  const int grid = stream_grid(npix * 2, 256);
-  if (Co <= 2) {      // (the reference's head has two outputs: half the weight / accumulator registers of the general form)
-    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_fwd_kernel<T, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, scale, shift, w, b,
-                                         out, tanh0, HW, C, Co, npix));
-  } else {
-    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_fwd_kernel<T, HEAD_MAX_CO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, scale, shift, w, b,
-                                         out, tanh0, HW, C, Co, npix));
-  }
+  const int pixb = npix >= ((int64_t)1 << 20) ? 1024 : 128;
+  const dim3 grid(ceil_div(npix, pixb));
+  // (the reference's head has two outputs: MC = 2 holds half the weight / accumulator registers of the general form; EX: Co == MC)
+#define MAU_HEAD_FWD(MC_, EX_)                                                                                                              \
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_fwd_kernel<T, MC_, EX_>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, scale, shift, w, b, \
+                                       out, tanh0, HW, C, Co, npix, pixb))
+  if (Co == 2) MAU_HEAD_FWD(2, true);
+  else if (Co == 1) MAU_HEAD_FWD(2, false);
+  else if (Co == HEAD_MAX_CO) MAU_HEAD_FWD(HEAD_MAX_CO, true);
+  else MAU_HEAD_FWD(HEAD_MAX_CO, false);
+#undef MAU_HEAD_FWD
   return check_launch("head_bn_fwd_kernel");
 }
 
@@ -597,16 +613,16 @@ int mau_head_bn_bwd_reduce(const void* y, int ldy, const float* scale, const flo
               mau_head_bn_max_channels());
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && ldy >= C8 && ldslab >= C, "head_bn_bwd_reduce: bad ld");
+  MAU_REQUIRE(HW >= 32 && (int64_t)N * HW < ((int64_t)1 << 31), "head_bn_bwd_reduce: images of at least 32 pixels, fewer than 2^31 pixels in all");
   const int64_t npix = (int64_t)N * HW;
-  if (Co <= 2) {
-    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_reduce_kernel<T, 2>), dim3(ceil_div(npix, BWD_PIX_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)y, ldy, scale, shift, mean, invstd, w, out, dout, bn_slab, ldslab, head_slab, tanh0, HW, C, C8,
-                                         Co, npix));
-  } else {
-    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_reduce_kernel<T, HEAD_MAX_CO>), dim3(ceil_div(npix, BWD_PIX_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)y, ldy, scale, shift, mean, invstd, w, out, dout, bn_slab, ldslab, head_slab, tanh0, HW, C, C8,
-                                         Co, npix));
-  }
+#define MAU_HEAD_RED(MC_, EX_)                                                                                                              \
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_reduce_kernel<T, MC_, EX_>), dim3(ceil_div(npix, BWD_PIX_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, \
+                                       (const T*)y, ldy, scale, shift, mean, invstd, w, out, dout, bn_slab, ldslab, head_slab, tanh0, HW, C, C8, Co, npix))
+  if (Co == 2) MAU_HEAD_RED(2, true);
+  else if (Co == 1) MAU_HEAD_RED(2, false);
+  else if (Co == HEAD_MAX_CO) MAU_HEAD_RED(HEAD_MAX_CO, true);
+  else MAU_HEAD_RED(HEAD_MAX_CO, false);
+#undef MAU_HEAD_RED
   return check_launch("head_bn_bwd_reduce_kernel");
 }
 
@@ -619,17 +635,17 @@ int mau_head_bn_bwd_apply(const void* y, int ldy, const float* scale, const floa
               mau_head_bn_max_channels());
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && ldy >= C8 && lddy % 8 == 0 && lddy >= C8, "head_bn_bwd_apply: bad ld");
+  MAU_REQUIRE(HW >= 32 && (int64_t)N * HW < ((int64_t)1 << 31), "head_bn_bwd_apply: images of at least 32 pixels, fewer than 2^31 pixels in all");
   const int64_t npix = (int64_t)N * HW;
   const int pixb = npix >= ((int64_t)1 << 20) ? 1024 : 256;   // 32 (8) pixels per thread: the coefficient set-up is paid once per thread
-  if (Co <= 2) {
-    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_apply_kernel<T, 2>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy,
-                                         scale, shift, mean, invstd, sums, count > 0 ? 1.0 / count : 0.0, w, out, dout, (T*)dy, lddy, tanh0, HW, C,
-                                         Co, npix, pixb));
-  } else {
-    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_apply_kernel<T, HEAD_MAX_CO>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy,
-                                         scale, shift, mean, invstd, sums, count > 0 ? 1.0 / count : 0.0, w, out, dout, (T*)dy, lddy, tanh0, HW, C,
-                                         Co, npix, pixb));
-  }
+#define MAU_HEAD_APPLY(MC_, EX_)                                                                                                            \
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_apply_kernel<T, MC_, EX_>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, \
+                                       scale, shift, mean, invstd, sums, count > 0 ? 1.0 / count : 0.0, w, out, dout, (T*)dy, lddy, tanh0, HW, C, Co, npix, pixb))
+  if (Co == 2) MAU_HEAD_APPLY(2, true);
+  else if (Co == 1) MAU_HEAD_APPLY(2, false);
+  else if (Co == HEAD_MAX_CO) MAU_HEAD_APPLY(HEAD_MAX_CO, true);
+  else MAU_HEAD_APPLY(HEAD_MAX_CO, false);
+#undef MAU_HEAD_APPLY
   return check_launch("head_bn_bwd_apply_kernel");
 }
 

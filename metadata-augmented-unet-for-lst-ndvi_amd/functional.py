@@ -464,7 +464,7 @@ class ConvBNReLU(torch.autograd.Function):
 
         # ---- the activation stage ----
         fused = _FUSED_BN
-        fuse_head = fused and st.head is not None and Cout <= lib.mau_head_bn_max_channels()
+        fuse_head = fused and st.head is not None and Cout <= lib.mau_head_bn_max_channels() and H * W >= 32
         fuse_up = fused and _FUSED_UP and st.up_to is not None and H <= st.up_to[0] and W <= st.up_to[1]
         a = pl = out = up = argidx = None
         if fuse_head:                                    # the head reads y and applies BatchNorm + ReLU on the fly: no activation tensor
