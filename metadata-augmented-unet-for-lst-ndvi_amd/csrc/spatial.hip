@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ d
 // (A forward kernel with a 2x2 block of destination pixels per thread -- 9 loads for 4 outputs instead of 16 -- measured
 //  7 % SLOWER than resize_fwd_kernel: the forward is bound by its 4x larger write stream, not by its loads.)
 // (Measured on top of the row-wise loads below: also skipping the zero-weight ROWS of an accumulator +9 % time -- kept only the
-//  column test.)
+//  column test.  Round 3, same-box: the column test as a select on the data instead of an exec-masked branch +17 % time; three
+//  waves per SIMD instead of two (launch bounds: 168 registers) +17 %; both together 5.9x -- scripts/resize_bench.py.)
 // (Also measured and dropped: an LDS-tiled adjoint -- 16x8 source pixels x 4 channel vectors per workgroup, the destination
 //  region and the per-row / per-column (index, weight) tables staged in LDS once -- ran 1.6x SLOWER than this kernel at
 //  C = 128..512 (64-byte pieces of every pixel row per workgroup), equal at C = 1024.)
