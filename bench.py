@@ -69,9 +69,10 @@ class ConvTimer:
                 Cin, Cout, N, H, W = args[2] + args[5] + args[8], args[11], args[14], args[15], args[16]
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
+                ws = torch.cuda.ExternalStream(args[-1])          # (the weight gradient may be launched on its own stream)
+                e0.record(ws)
                 orig(name, *args)
-                e1.record()
+                e1.record(ws)
                 # algorithmic bytes of the launch: X and dY read once (16-bit), dW written once (fp32)
                 self.wbytes = getattr(self, "wbytes", 0.0) + (Cin + Cout) * N * H * W * 2.0 + 9.0 * Cin * Cout * 4.0
                 self.wrecords.append((e0, e1, conv_flops(N, H, W, Cin, Cout)))
@@ -299,6 +300,7 @@ def main():
         # batch, same kernels) right after the timed region, with the event brackets, for the per-kernel durations.
         opt.zero_grad(set_to_none=True)
         timer.enabled = True
+        overlap, F_._OVERLAP_WGRAD = F_._OVERLAP_WGRAD, 0          # one stream: a kernel's events bracket that kernel alone
         for i in range(args.steps):
             out = net(x, ts, md)
             loss = mau_amd.compute_loss_mse(out, tgt)["total"]
@@ -311,6 +313,7 @@ def main():
             opt.zero_grad()
         torch.cuda.synchronize()
         timer.enabled = False
+        F_._OVERLAP_WGRAD = overlap
         timing_pass = (f"HIP events on the launch stream around every launch over {args.steps} eager steps of the same workload run "
                        "right after the timed region (the timed steps are hipGraph replays, which cannot carry timing events)")
     if world > 1:

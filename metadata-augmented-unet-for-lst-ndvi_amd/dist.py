@@ -24,6 +24,7 @@ SURVEY D4) keep ``grad is None`` exactly as in the reference; their arena slots 
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, List, Optional
 
 import torch
@@ -52,6 +53,11 @@ class _Bucket:
         self.handle = None
         self.launched = False
         self.streams = []
+
+
+def _grad_sync_gone():
+    from . import functional as F_
+    F_._GRAD_SYNC_ACTIVE[0] -= 1
 
 
 class GradSync:
@@ -95,6 +101,11 @@ class GradSync:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._active = False
         self._avg = self.group is not None and dist.get_backend(self.group) == "nccl"
+        self._counted = None
+        if self.group is not None:
+            from . import functional as F_
+            F_._GRAD_SYNC_ACTIVE[0] += 1          # (the weight-gradient side stream stays off while buckets are launched inside backward)
+            self._counted = weakref.finalize(self, _grad_sync_gone)      # remove() or garbage collection, whichever comes first
 
     # ------------------------------------------------------------------ #
     def begin(self):
@@ -138,6 +149,9 @@ class GradSync:
             s = torch.cuda.current_stream(p.device)
             if s not in b.streams:
                 b.streams.append(s)
+            ws = getattr(p, "_mau_grad_stream", None)       # the gradient is still being written on the weight-gradient stream
+            if ws is not None and ws not in b.streams:
+                b.streams.append(ws)
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
@@ -164,6 +178,9 @@ class GradSync:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._counted is not None:
+            self._counted()                       # (a finalizer runs once)
+            self._counted = None
         for p in self.params:
             if hasattr(p, "_mau_grad_slot"):
                 del p._mau_grad_slot

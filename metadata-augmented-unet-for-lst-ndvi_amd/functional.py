@@ -10,6 +10,7 @@ fuse_embeddings :248-259, head :284-292), src/utils/losses.py:27-39.
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 
 import os
@@ -306,11 +307,19 @@ def _all_reduce_(t: torch.Tensor, st: BNState):
         all_reduce_sum(t, st.group)
 
 
-_OVERLAP_WGRAD = os.environ.get("MAU_OVERLAP_WGRAD", "0") != "0"      # measured: ~1 % (profiles/r1), off by default
+# Weight gradients on a side stream.  "1": beside the data gradient of the same layer, joined before the block's backward returns
+# (two MFMA kernels compete for the same pipes: ~1 %, profiles/r1).  "2": NOT joined per layer -- the weight-gradient chain (MFMA-bound)
+# runs beside everything the main stream does next, notably the HBM-bound BatchNorm-backward passes of the following layers; one
+# join when the backward pass ends (autograd engine callback).  Same kernels, same arithmetic: bit-identical.  Measured (one box,
+# B=32 U-Net step): eager 13.80 -> 12.93 ms (the second stream fills the launch gaps of the first), hipGraph 12.93 -> 12.85 ms
+# (a 227-register weight-gradient wave leaves no room for a BatchNorm wave on its SIMD: the kernels share the chip by CU, not by
+# issue slot).  Default "2"; "0" = one stream.
+_OVERLAP_WGRAD = int(os.environ.get("MAU_OVERLAP_WGRAD", "2") or 0)
 _FUSED_REDUCE = os.environ.get("MAU_FUSED_REDUCE", "1") != "0"        # single-launch slab reductions (A/B switch; bit-identical)
 _FUSED_BN = os.environ.get("MAU_FUSED_BN", "1") != "0"                # BatchNorm passes fused with pool / head / upsample (A/B switch; bit-identical)
 _FUSED_UP = os.environ.get("MAU_FUSED_UP", "1") != "0"                # (the upsample member of the above, separately switchable)
 _SIDE_STREAMS = {}
+_GRAD_SYNC_ACTIVE = [0]              # number of live dist.GradSync objects with a process group
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":
@@ -318,6 +327,17 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     if s is None:
         s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
     return s
+
+
+def _join_side_when_backward_ends(dev):
+    """Queue the join of the weight-gradient stream: the engine runs the callback on the thread that called backward(), after the
+    last node -- whatever follows on that thread's stream (any optimizer, a gradient clip, a collective) sees finished gradients.
+    One callback per deferred launch, no state kept between passes (a backward pass that raises never runs its callbacks: a
+    "queued already" flag would then stay set and silently drop the join of every later pass); waits after the first are no-ops."""
+    def join():
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+
+    torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
 def _conv_fwd(x, x1, st, emb, emb_ws, E, wpk, bias, post, y, Cout, slab, code, N, H, W, stream):
@@ -628,24 +648,38 @@ class ConvBNReLU(torch.autograd.Function):
         # --- weight gradient: independent of the data gradient given dy ---
         dw = None
         need_dx = needs[0] or (x1 is not None and needs[1]) or (E and needs[2])
-        side = _side_stream(dev) if (needs[3] and need_dx and _OVERLAP_WGRAD) else None
+        # (under dist.GradSync the buckets' all-reduces are launched DURING backward and would each wait for the side stream: measured
+        #  15.1 vs 14.2 ms on the one-rank rehearsal -- one stream there)
+        overlap = 0 if _GRAD_SYNC_ACTIVE[0] else _OVERLAP_WGRAD
+        side = _side_stream(dev) if (needs[3] and overlap and (need_dx or overlap >= 2)) else None
+        deferred = False
         if needs[3]:
-            acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), **f32)
-            emb_ws = torch.empty((N, E), dtype=y.dtype, device=dev) if E else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())           # dy is complete
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                # (workspaces of the side stream's kernels belong to ITS allocator pool: freed here, re-used there)
+                acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), **f32)
+                emb_ws = torch.empty((N, E), dtype=y.dtype, device=dev) if E else None
             # data parallel (dist.GradSync): the split-K sum is written straight into the parameter's slot of the gradient arena
             # and autograd adopts the returned view as weight.grad -- no copy into the arena later.  Only for the FIRST
             # gradient of a step: an accumulating backward (weight.grad already set) must not overwrite what it adds to.
             slot = getattr(weight, "_mau_grad_slot", None)
             dw = slot.view_as(weight) if (slot is not None and weight.grad is None and slot.device == dev) else torch.empty_like(weight)
-            wstream = stream
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())
-                wstream = side.cuda_stream
+            wstream = side.cuda_stream if side is not None else stream
+            # deferred join: only where the gradient is ASSIGNED (arena slot adopted as weight.grad, or a fresh tensor) -- an
+            # accumulating AccumulateGrad would add on the main stream to what the side stream is still writing
+            deferred = side is not None and overlap >= 2 and weight.grad is None
             call("mau_conv3x3_wgrad2", x.data_ptr(), _ld(x), st.C0, x1.data_ptr() if x1 is not None else None,
                  _ld(x1) if x1 is not None else 0, C1, emb.data_ptr() if E else None,
                  emb_ws.data_ptr() if E else None, E, dy.data_ptr(), ldy, Cout, acc.data_ptr(), code, N, H, W, wstream)
             call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin),
                  dw.data_ptr(), Cout, Cin, wstream)
+            if deferred:
+                for t in (x, x1, emb, dy, dw):                           # read / written over there after this function has returned
+                    if t is not None:
+                        t.record_stream(side)
+                weight._mau_grad_stream = side                           # (dist.GradSync: the bucket's launch waits for it)
+                _join_side_when_backward_ends(dev)
         # --- data gradient (same implicit-GEMM kernel, rotated/transposed weight pack) ---
         dx = dx1 = demb = None
         if need_dx:
@@ -667,7 +701,7 @@ class ConvBNReLU(torch.autograd.Function):
                     dx1 = dfull[..., st.C0:st.C0 + pad8(C1)]
             elif needs[0]:
                 dx = dfull[..., :pad8(st.C0)] if E else dfull           # C0 % 8 == 0 is enforced by the kernel when E > 0
-        if side is not None:
+        if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)
         dbias = None
         if needs[4]:
