@@ -313,7 +313,8 @@ def _all_reduce_(t: torch.Tensor, st: BNState):
 # join when the backward pass ends (autograd engine callback).  Same kernels, same arithmetic: bit-identical.  Measured (one box,
 # B=32 U-Net step): eager 13.80 -> 12.93 ms (the second stream fills the launch gaps of the first), hipGraph 12.93 -> 12.85 ms
 # (a 227-register weight-gradient wave leaves no room for a BatchNorm wave on its SIMD: the kernels share the chip by CU, not by
-# issue slot).  Default "2"; "0" = one stream.
+# issue slot).  The eager figure depends on the host: on a box with a slow / busy CPU the extra stream bookkeeping made the eager
+# step SLOWER (17-18 vs 14-16 ms); the captured step does not care.  Default "2"; "0" = one stream.
 _OVERLAP_WGRAD = int(os.environ.get("MAU_OVERLAP_WGRAD", "2") or 0)
 _FUSED_REDUCE = os.environ.get("MAU_FUSED_REDUCE", "1") != "0"        # single-launch slab reductions (A/B switch; bit-identical)
 _FUSED_BN = os.environ.get("MAU_FUSED_BN", "1") != "0"                # BatchNorm passes fused with pool / head / upsample (A/B switch; bit-identical)
