@@ -103,8 +103,14 @@ class GraphedTrainStep:
             F_.mark_params_updated()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
+        # Under a process group another thread of this process talks to the runtime while we capture: ProcessGroupNCCL's watchdog
+        # polls the events of earlier collectives (hipEventQuery).  In the default "global" capture mode that call is an error in ANY
+        # thread while a capture is open -- the watchdog dies and takes the process with it (seen as a sporadic SIGABRT, depending on
+        # whether the last warm-up step's collectives had been reaped yet).  "thread_local" restricts the check to the capturing thread.
+        import torch.distributed as dist
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=mode):
                 outputs = self.model(self._in[0], self._in[1], self._in[2])
                 loss = self._loss_of(outputs, self._in[3])
                 if self.grad_sync is not None:
