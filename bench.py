@@ -69,7 +69,9 @@ class ConvTimer:
                 Cin, Cout, N, H, W = args[2] + args[5] + args[8], args[11], args[14], args[15], args[16]
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
-                ws = torch.cuda.ExternalStream(args[-1])          # (the weight gradient may be launched on its own stream)
+                # (the weight gradient may be launched on its own stream: the events go where the kernel goes)
+                cur = torch.cuda.current_stream()
+                ws = cur if args[-1] == cur.cuda_stream else torch.cuda.ExternalStream(args[-1])
                 e0.record(ws)
                 orig(name, *args)
                 e1.record(ws)

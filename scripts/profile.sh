@@ -8,6 +8,7 @@ TAG=${1:-r3}; shift || true
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export MAU_OVERLAP_WGRAD=0      # one stream: per-kernel times and counters belong to one kernel at a time
 BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
 echo "$BENCH" > "$OUT/command.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1

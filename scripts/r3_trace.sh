@@ -4,6 +4,7 @@ set -u
 TAG=$1; shift
 O=gpurun_out/r3_trace_$TAG; mkdir -p $O
 export TMPDIR=/tmp
+export MAU_OVERLAP_WGRAD=0      # one stream: per-kernel times and counters belong to one kernel at a time
 for e in "$@"; do export "$e"; done
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $O/trace.log 2>&1
 echo "trace rc=$?"
