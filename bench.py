@@ -289,7 +289,11 @@ def main():
         sys.stdout.write(proc.stdout)
         raise SystemExit(proc.returncode)
     barrier()
-    timer.enabled = graphed is None
+    # per-kernel events inside the timed region only when every kernel has the GPU to itself there: not under a graph replay (no
+    # events in a graph) and not with the weight gradients on their own stream (two kernels share the chip: neither's events
+    # measure it alone) -- then the same K steps are launched again afterwards, eagerly, on one stream, with the brackets
+    separate_pass = (graphed is not None or (F_._OVERLAP_WGRAD and sync is None)) and not args.infer
+    timer.enabled = not separate_pass
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -297,9 +301,9 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     timing_pass = "HIP events on the launch stream around every launch, inside the timed region"
-    if graphed is not None:
-        # A captured graph cannot carry timing events: the same K steps are launched eagerly (kernel by kernel, same resident
-        # batch, same kernels) right after the timed region, with the event brackets, for the per-kernel durations.
+    if separate_pass:
+        # the same K steps launched eagerly (kernel by kernel, same resident batch, same kernels, ONE stream) right after the timed
+        # region, with the event brackets, for the per-kernel durations
         opt.zero_grad(set_to_none=True)
         timer.enabled = True
         overlap, F_._OVERLAP_WGRAD = F_._OVERLAP_WGRAD, 0          # one stream: a kernel's events bracket that kernel alone
@@ -317,7 +321,7 @@ def main():
         timer.enabled = False
         F_._OVERLAP_WGRAD = overlap
         timing_pass = (f"HIP events on the launch stream around every launch over {args.steps} eager steps of the same workload run "
-                       "right after the timed region (the timed steps are hipGraph replays, which cannot carry timing events)")
+                       "on one stream right after the timed region (the timed steps are hipGraph replays / run the weight gradients on a second stream)")
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
