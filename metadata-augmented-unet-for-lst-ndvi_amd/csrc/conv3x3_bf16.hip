@@ -274,9 +274,13 @@ __device__ __forceinline__ void dma_issue_buf(__amdgpu_buffer_rsrc_t rs, int vof
 #endif
 }
 
-template <int BN, int MT, int NW, int EPI, bool F16, bool FAST, bool M16>
+// ONE: the layer reads ONE tensor (no second source, no broadcast embedding) -- every data gradient and all but five forward launches
+// of a step.  The per-DMA choice of the source then disappears from the multiply loop (it was 38 scalar compare-and-branch pairs per
+// stage pair between the MFMAs: -1.5...3 % of a launch), with it the second source's lane offsets (5 registers).
+template <int BN, int MT, int NW, int EPI, bool F16, bool FAST, bool M16, bool ONE = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
   static_assert(!M16 || (MT == 4 && NW == 8 && FAST), "the 16x16x32 loop: 128-pixel wave strips, buffer-addressed loader");
+  static_assert(!ONE || M16, "single-source instantiations exist for the 16x16x32 variants only");
   using G = Geo<BN, MT, NW>;
   constexpr int WN = G::WN, WM = G::WM, TH = G::TH, HPIX = G::HPIX, HALO_Q = G::HALO_Q, HALO_BYTES = G::HALO_BYTES;
   constexpr int TOT_Q = G::TOT_Q, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
     for (int j = 0; j < PER_WAVE; ++j) {
       const int q = wave + j * NW;
       off32[j] = -1;
-      if (j < HJ) off1[j < HJ ? j : 0] = -1;
+      if (!ONE && j < HJ) off1[j < HJ ? j : 0] = -1;
       int hp_or_row, sc;
       slot_of(j, hp_or_row, sc);
       if (q < HALO_Q) {
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
           if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv) {
             const int pix = (it.n * Hv + gy) * Wv + gx;
             off32[j] = fast ? pix * (int)(2 * ld0v) + 2 * sc : pix;
-            if (j < HJ) off1[j < HJ ? j : 0] = pix * (int)(2 * ld1v) + 2 * sc;
+            if (!ONE && j < HJ) off1[j < HJ ? j : 0] = pix * (int)(2 * ld1v) + 2 * sc;
           }
         }
       } else if (q < TOT_Q) {
@@ -416,7 +420,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
       dma_issue_buf(rs_w, off32[(J)], (CHUNK_) * w_stage_bytes32, dst_);                                              \
     } else if constexpr (FAST) {                                                                                       \
       if constexpr ((J) < HJ) {                                                                                        \
-        if (c0_ >= Ctot) dma_issue_buf(rs_e, off32[(J)] < 0 ? -1 : (off32[(J)] & 16), embn_off + 2 * (c0_ - Ctot), dst_); \
+        if constexpr (ONE) dma_issue_buf(rs_x, off32[(J)], 2 * c0_, dst_);                                           \
+        else if (c0_ >= Ctot) dma_issue_buf(rs_e, off32[(J)] < 0 ? -1 : (off32[(J)] & 16), embn_off + 2 * (c0_ - Ctot), dst_); \
         else if (hasC1 && c0_ >= C0v) dma_issue_buf(rs_x1, off1[(J) < HJ ? (J) : 0], 2 * (c0_ - C0v), dst_);           \
         else dma_issue_buf(rs_x, off32[(J)], 2 * c0_, dst_);                                                          \
       }                                                                                                                \
@@ -912,7 +917,10 @@ static int launch(const ConvP& p, hipStream_t st) {
   using G = Geo<BN, MT, NW>;
   MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, false>);
   MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false, false>);
-  if constexpr (MT == 4 && NW == 8) MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>);
+  if constexpr (MT == 4 && NW == 8) {
+    MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>);
+    MAU_LDS_ATTR(G::LDS, (&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true, true>));
+  }
   const DeviceShape ds = device_shape();
   const int tilesX = ceil_div(p.W, TW), tilesY = ceil_div(p.H, G::TH);
   ConvP q = p;
@@ -946,7 +954,11 @@ static int launch(const ConvP& p, hipStream_t st) {
   bool done = false;
   if constexpr (MT == 4 && NW == 8) {
     if (m16 && q.fast && q.nChunks % 2 == 0) {
-      MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+      static const bool no_one = getenv("MAU_CONV_ONE") != nullptr && atoi(getenv("MAU_CONV_ONE")) == 0;      // A/B switch
+      if (p.C1 == 0 && p.E == 0 && !no_one)
+        MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+      else
+        MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
       done = true;
     }
   }
