@@ -234,7 +234,12 @@ def main():
         sync = GradSync(net, dist.group.WORLD)
     losses = torch.zeros(args.steps + args.warmup, device=dev)
 
+    session = [None]            # --infer on one GPU: the app's path, an inference.GraphedInference session (one hipGraph replay per call)
+
     def infer_step(i):
+        if session[0] is not None:
+            session[0](x, ts, md)
+            return
         with torch.no_grad():
             net(x, ts, md)
 
@@ -264,6 +269,8 @@ def main():
 
     if args.infer:
         net.eval().freeze_inference()      # inference session: packed weights / folded BN coefficients computed once
+        if world == 1 and not args.no_graph:
+            session[0] = mau_amd.GraphedInference(net, x, ts, md)
     timer = ConvTimer(F_)
     timer.install()
 
@@ -292,7 +299,7 @@ def main():
     # per-kernel events inside the timed region only when every kernel has the GPU to itself there: not under a graph replay (no
     # events in a graph) and not with the weight gradients on their own stream (two kernels share the chip: neither's events
     # measure it alone) -- then the same K steps are launched again afterwards, eagerly, on one stream, with the brackets
-    separate_pass = (graphed is not None or (F_._OVERLAP_WGRAD and sync is None)) and not args.infer
+    separate_pass = session[0] is not None if args.infer else (graphed is not None or (F_._OVERLAP_WGRAD and sync is None))
     timer.enabled = not separate_pass
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -308,6 +315,10 @@ def main():
         timer.enabled = True
         overlap, F_._OVERLAP_WGRAD = F_._OVERLAP_WGRAD, 0          # one stream: a kernel's events bracket that kernel alone
         for i in range(args.steps):
+            if args.infer:
+                with torch.no_grad():
+                    net(x, ts, md)
+                continue
             out = net(x, ts, md)
             loss = mau_amd.compute_loss_mse(out, tgt)["total"]
             if sync is not None:
@@ -404,7 +415,9 @@ def main():
                                 + ("eval-mode forward only (inference)" if args.infer else "fwd+MSE+bwd+AdamW (src/train.py:243-256)")),
                    "global_batch": B * world, "parallelism": f"dp{world}" + (" (data-parallel path forced under a 1-rank RCCL group)" if args.force_dist and world == 1 else ""),
                    "sync_bn": bool(world > 1 and not args.no_sync_bn),
-                   "launch": "hipGraph replay of the captured step" if graphed is not None else "eager (kernel by kernel)"},
+                   "launch": ("hipGraph replay of the captured step" if graphed is not None else
+                              "hipGraph replay (GraphedInference session: input copies + replay + output clone per call)" if session[0] is not None
+                              else "eager (kernel by kernel)")},
         "rccl_ranks": rccl_ranks,
         "fwd_ms_per_tile": round(fwd_ms_per_tile, 4),
         "final_loss": float(losses[-1]),
