@@ -275,7 +275,9 @@ __device__ __forceinline__ void pos_step32(int& n, int& q, int HW) {
 // 32nd pixel, four pixels per iteration (their loads are issued together).  After the 8-lane butterfly every lane of a pixel holds the
 // pixel's Co sums; lane `sub` (0..3) then finishes pixel u = sub of the iteration -- bias, tanh, store -- so that tanhf and the
 // address arithmetic run once per FOUR pixels instead of once per pixel (they are exec-masked scalar code: the wave pays in full).
-template <typename T, int MC, bool EX>
+// BN = false: the input IS the activation (eval mode: BatchNorm + ReLU were folded into the convolution's epilogue) -- the plain 1x1
+// head, mau_head_fwd's fast path.
+template <typename T, int MC, bool EX, bool BN = true>
 __global__ __launch_bounds__(256) void head_bn_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ w,
                                                           const float* __restrict__ b, float* __restrict__ out, int tanh0, int HW, int C,
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256) void head_bn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) wr[o][j] = (EX || o < Co) ? coef(w + o * C, sub * 8 + j, C) : 0.f;
   Coef8 k;
-  k.load(scale, shift, nullptr, nullptr, sub * 8, C);
+  if (BN) k.load(scale, shift, nullptr, nullptr, sub * 8, C);
   float bo[MC];
 #pragma unroll
   for (int o = 0; o < MC; ++o) bo[o] = (EX || o < Co) ? b[o] : 0.f;
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void head_bn_fwd_kernel(const T* __restrict__ 
       if (sub * 8 < C) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float a = round_to<T>(fmaxf(fmaf(x[u].v[j], k.sc[j], k.sh[j]), 0.f));
+          const float a = BN ? round_to<T>(fmaxf(fmaf(x[u].v[j], k.sc[j], k.sh[j]), 0.f)) : x[u].v[j];
 #pragma unroll
           for (int o = 0; o < MC; ++o) acc[u][o] = fmaf(a, wr[o][j], acc[u][o]);
         }
@@ -528,6 +530,23 @@ __global__ __launch_bounds__(256) void head_bn_bwd_apply_kernel(const T* __restr
     one(p, v, dz);
     pos_step32(n, q, HW);
   }
+}
+
+// mau_head_fwd's fast path (head.hip): heads of at most 64 channels on images of at least 32 pixels
+int head_fwd_fast(const void* a, int lda, const float* w, const float* b, float* out, int tanh0, int dtype, int64_t npix, int HW, int C, int Co,
+                  hipStream_t stream) {
+  const int pixb = npix >= ((int64_t)1 << 20) ? 1024 : 128;
+  const dim3 grid(ceil_div(npix, pixb));
+  const float* none = nullptr;
+#define MAU_HEAD_PLAIN(MC_, EX_)                                                                                                            \
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_fwd_kernel<T, MC_, EX_, false>), grid, dim3(256), 0, stream, (const T*)a, lda, none, none, w, b, out, \
+                                       tanh0, HW, C, Co, npix, pixb))
+  if (Co == 2) MAU_HEAD_PLAIN(2, true);
+  else if (Co == 1) MAU_HEAD_PLAIN(2, false);
+  else if (Co == HEAD_MAX_CO) MAU_HEAD_PLAIN(HEAD_MAX_CO, true);
+  else MAU_HEAD_PLAIN(HEAD_MAX_CO, false);
+#undef MAU_HEAD_PLAIN
+  return check_launch("head_fwd_kernel");
 }
 
 }  // namespace mau

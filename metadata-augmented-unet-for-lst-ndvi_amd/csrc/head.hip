@@ -376,6 +376,10 @@ int mau_head_fwd(const void* a, int lda, const float* w, const float* b, float* 
   MAU_REQUIRE(Co >= 1 && Co <= HEAD_MAX_CO, "head_fwd: out_channels must be in [1,%d]", HEAD_MAX_CO);
   MAU_REQUIRE(lda % 8 == 0 && lda >= round_up(C, 8), "head_fwd: bad ld");
   const int64_t npix = (int64_t)N * HW;
+  // heads of at most 64 channels (every model of the reference): four pixels per thread and iteration, no per-pixel division
+  // (bn_fused.hip: head_bn_fwd_kernel<..., BN = false>, the same arithmetic in the same order)
+  if (C <= mau_head_bn_max_channels() && HW >= 32 && npix < ((int64_t)1 << 31))
+    return head_fwd_fast(a, lda, w, b, out, tanh0, dtype, npix, HW, C, Co, (hipStream_t)stream);
   const int grid = stream_grid(npix * 8, 256);
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(head_fwd_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, w, b, out, tanh0, HW, C, Co, npix));
   return check_launch("head_fwd_kernel");

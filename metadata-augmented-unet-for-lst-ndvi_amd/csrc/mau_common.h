@@ -247,6 +247,10 @@ static inline int stream_grid(int64_t work_items, int block) {
   return (int)g;
 }
 
+// bn_fused.hip: the 1x1 head on an activation tensor (no BatchNorm), fast path of mau_head_fwd
+int head_fwd_fast(const void* a, int lda, const float* w, const float* b, float* out, int tanh0, int dtype, int64_t npix, int HW, int C, int Co,
+                  hipStream_t stream);
+
 }  // namespace mau
 
 #define MAU_DISPATCH_DTYPE(dtype, ...)              \
