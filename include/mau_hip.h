@@ -222,7 +222,9 @@ int mau_pool_bn_bwd_apply(const void* y, int ldy, const void* dpl, int lddpl, co
  * mau_head_bn_max_channels()): out = head(relu(scale*y + shift)) from the RAW conv output y -- the activation is never
  * written; backward in two passes over y: (1) BatchNorm partial sums (slab as mau_bn_relu_bwd_reduce) + the head's dW / db
  * partials (head_slab as mau_head_bwd), (2) dy of the conv; da = W^T dz is recomputed from dout both times.  Bit-identical
- * to mau_bn_relu_apply + mau_head_fwd / mau_head_bwd + mau_bn_relu_bwd_reduce + mau_bn_relu_bwd_apply. */
+ * to mau_bn_relu_apply + mau_head_fwd / mau_head_bwd + mau_bn_relu_bwd_reduce + mau_bn_relu_bwd_apply.
+ * Images of at least 32 pixels (HW >= 32) and N * HW < 2^31: a thread walks pixels in steps of 32 with one conditional wrap into
+ * the next image (smaller images: the separate kernels). */
 int mau_head_bn_max_channels(void);
 int mau_head_bn_fwd(const void* y, int ldy, const float* scale, const float* shift, const float* w, const float* b, float* out,
                     int tanh0, int dtype, int N, int HW, int C, int Co, mau_stream_t stream);
