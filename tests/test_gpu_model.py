@@ -780,6 +780,41 @@ def test_inplace_op_on_a_row_buffer_raises_in_backward(mau, monkeypatch):
         out.float().sum().backward()
 
 
+def test_weight_gradient_stream_is_bitwise_neutral(mau, monkeypatch):
+    """functional._OVERLAP_WGRAD = 2: the weight gradients of a backward pass run on their own stream and join ONCE, from an autograd
+    engine callback when the pass has ended.  Same kernels: three optimizer steps -- the second with gradient ACCUMULATION (two
+    backward passes before the step: the accumulating pass must fall back to the per-layer join, it adds on the main stream) --
+    must leave bit-identical gradients, parameters and BatchNorm buffers to the one-stream run; torch's AdamW (no gradient arena)
+    and mau_amd.AdamW (arena slots) both."""
+    from mau_amd import functional as F_
+    g = torch.Generator().manual_seed(81)
+    data = [(torch.randn(2, 6, 48, 40, generator=g).cuda(), torch.randn(2, 10, generator=g).cuda(), torch.randn(2, 4, generator=g).cuda(),
+             torch.randn(2, 2, 48, 40, generator=g).cuda()) for _ in range(4)]
+    for arena in (False, True):
+        res = []
+        for mode in (0, 2):
+            monkeypatch.setattr(F_, "_OVERLAP_WGRAD", mode)
+            torch.manual_seed(80)
+            net = mau.UrbanPredictor("unet", 6, 10, 16, 4, 16, 24, 2, base_filters=16, temporal_embeddings=True).cuda().set_precision("bf16").train()
+            opt = mau.AdamW(net.parameters(), lr=1e-3) if arena else torch.optim.AdamW(net.parameters(), lr=1e-3, fused=True)
+            grads = []
+            for step, passes in enumerate((1, 2, 1)):
+                for k in range(passes):
+                    x, ts, md, tgt = data[step + k]
+                    mau.compute_loss_mse(net(x, ts, md), tgt)["total"].backward()
+                grads.append({n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+                opt.step()
+                opt.zero_grad()
+            torch.cuda.synchronize()
+            res.append((grads, {k: v.clone() for k, v in net.state_dict().items()}))
+        for ga, gb in zip(res[0][0], res[1][0]):
+            assert ga.keys() == gb.keys()
+            for k in ga:
+                assert torch.equal(ga[k], gb[k]), (arena, k)
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], res[1][1][k]), (arena, k)
+
+
 def test_single_launch_reductions_and_multi_pack_are_bit_identical(mau, monkeypatch):
     """Launch-tail fusions of round 3 against the forms they replace, same arithmetic in the same order: the single-launch slab
     reductions (ticket: the last workgroup runs the second level; functional._FUSED_REDUCE) vs two launches, and the one-launch
