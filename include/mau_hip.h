@@ -237,6 +237,17 @@ int mau_head_bn_bwd_apply(const void* y, int ldy, const float* scale, const floa
                           const float* dout, void* dy, int lddy, int tanh0, int dtype, int N, int HW, int C, int Co,
                           mau_stream_t stream);
 
+/* ---- the broadcast embedding of a convolution as a rank-one term (csrc/embfold.hip) ----
+ * fuse_embeddings / the U-Net++ nodes' emb_map (src/model.py:248-259, :111-121) put E spatially constant channels behind the tensors a
+ * 3x3 conv reads.  W_eff = [ W[:, :Ct] | T ], T[co][i][tap] = sum_e W[co][Ct+e][tap] * emb[i][e]  (Cout x (Ct+Ep) x 3 x 3, Ep >= N,
+ * columns i >= N zero): the same convolution over Ct tensor channels + the N x Ep IDENTITY as "embedding" gives the same output with
+ * Ct + Ep instead of Ct + E input channels.  bwd: dW (Cout x (Ct+E) x 3 x 3) and demb (N x E) from dW_eff (either may be NULL).
+ * fp32, fixed summation order. */
+int mau_emb_fold_fwd(const float* w, const float* emb, float* weff, int Cout, int Ct, int E, int N, int Ep, mau_stream_t stream);
+size_t mau_emb_fold_ws_elems(int Cout, int N, int E);   /* floats of ws (needed when demb is asked for) */
+int mau_emb_fold_bwd(const float* w, const float* emb, const float* dweff, float* dw, float* demb, float* ws, int Cout, int Ct, int E,
+                     int N, int Ep, mau_stream_t stream);
+
 /* ---- MaxPool2d(2,2) (src/model.py:57,218) -------------------------------- */
 int mau_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, int dtype, int N, int H, int W, int C,
                        mau_stream_t stream);

@@ -92,6 +92,9 @@ PROTOTYPES = {
     "mau_adamw_pack_desc_bytes": (_sz, []),
     "mau_adamw_pack_desc_fill": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "mau_adamw_pack_step": (_i, [_p, _i, _i, _i, _p, _f, _f, _f, _f, _f, _p]),
+    "mau_emb_fold_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mau_emb_fold_ws_elems": (_sz, [_i, _i, _i]),
+    "mau_emb_fold_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mau_mse_blocks": (_i, [_i64]),
     "mau_l1_gradient_blocks": (_i, [_i64]),
     "mau_l1_gradient_loss": (_i, [_p, _p, _p, _p, _p, _f, _f, _i, _i, _i, _i, _p]),

@@ -665,11 +665,12 @@ class ConvBNReLU(torch.autograd.Function):
             # and autograd adopts the returned view as weight.grad -- no copy into the arena later.  Only for the FIRST
             # gradient of a step: an accumulating backward (weight.grad already set) must not overwrite what it adds to.
             slot = getattr(weight, "_mau_grad_slot", None)
-            dw = slot.view_as(weight) if (slot is not None and weight.grad is None and slot.device == dev) else torch.empty_like(weight)
+            dw = slot.view_as(weight) if (slot is not None and weight.is_leaf and weight.grad is None and slot.device == dev) else torch.empty_like(weight)
             wstream = side.cuda_stream if side is not None else stream
             # deferred join: only where the gradient is ASSIGNED (arena slot adopted as weight.grad, or a fresh tensor) -- an
             # accumulating AccumulateGrad would add on the main stream to what the side stream is still writing
-            deferred = side is not None and overlap >= 2 and weight.grad is None
+            # (and only for a parameter: the gradient of a derived weight -- EmbFold's W_eff -- is read by ITS backward on the main stream)
+            deferred = side is not None and overlap >= 2 and weight.is_leaf and weight.grad is None
             call("mau_conv3x3_wgrad2", x.data_ptr(), _ld(x), st.C0, x1.data_ptr() if x1 is not None else None,
                  _ld(x1) if x1 is not None else 0, C1, emb.data_ptr() if E else None,
                  emb_ws.data_ptr() if E else None, E, dy.data_ptr(), ldy, Cout, acc.data_ptr(), code, N, H, W, wstream)
@@ -809,6 +810,84 @@ class RowPrefix(torch.autograd.Function):
     def backward(ctx, g):
         g = _as_nhwc(g)
         return (None, *[g[..., j * ctx.C:(j + 1) * ctx.C] for j in range(ctx.k)])
+
+
+class EmbFold(torch.autograd.Function):
+    """The broadcast embedding of a 3x3 convolution as a rank-one term (csrc/embfold.hip).
+
+    ``W_eff = EmbFold.apply(weight, emb, Ct, Ep)``: ``weight`` (Cout, Ct + E, 3, 3) convolves Ct tensor channels followed by the
+    E channels of ``emb`` (N, E) broadcast over the pixels (fuse_embeddings / the U-Net++ nodes' emb_map, src/model.py:248-259,
+    :111-121).  ``W_eff`` (Cout, Ct + Ep, 3, 3) = [weight[:, :Ct] | T] with T[co][i] = sum_e weight[co][Ct + e] * emb[i][e] gives the
+    SAME output when the convolution is run over the tensors and ``emb_identity(N, Ep)`` -- Ep = roundup(N, 16) indicator channels
+    instead of E constant ones (16 or 32 instead of 128: a third of the MACs of a U-Net++ decoder node, forward, data gradient and
+    weight gradient alike).  The backward maps dW_eff to dW and demb; nothing else in the path knows about the fold."""
+
+    @staticmethod
+    def forward(ctx, weight, emb, Ct: int, Ep: int):
+        _require_cuda(weight, "EmbFold")
+        w = weight.detach().contiguous().float()
+        e = emb.detach().contiguous().float()
+        Cout, Cf = w.shape[0], w.shape[1]
+        N, E = e.shape
+        if Cf != Ct + E or Ep < N:
+            raise RuntimeError(f"EmbFold: weight has {Cf} input channels, expected {Ct}+{E}; Ep={Ep} must cover the batch of {N}")
+        weff = torch.empty((Cout, Ct + Ep, 3, 3), dtype=torch.float32, device=w.device)
+        call("mau_emb_fold_fwd", w.data_ptr(), e.data_ptr(), weff.data_ptr(), Cout, Ct, E, N, Ep, _stream())
+        ctx.save_for_backward(weight, emb)
+        ctx.dims = (Cout, Ct, E, N, Ep)
+        return weff
+
+    @staticmethod
+    def backward(ctx, dweff):
+        weight, emb = ctx.saved_tensors
+        Cout, Ct, E, N, Ep = ctx.dims
+        dweff = dweff.contiguous().float()
+        w = weight.detach().contiguous().float()
+        e = emb.detach().contiguous().float()
+        dw = demb = None
+        if ctx.needs_input_grad[0]:
+            # (like ConvBNReLU: the FIRST gradient of a step is written straight into the parameter's slot of the gradient arena)
+            slot = getattr(weight, "_mau_grad_slot", None)
+            dw = slot.view_as(weight) if (slot is not None and weight.is_leaf and weight.grad is None and slot.device == w.device) else torch.empty_like(w)
+        ws = None
+        if ctx.needs_input_grad[1]:
+            demb = torch.empty((N, E), dtype=torch.float32, device=w.device)
+            ws = torch.empty(lib.mau_emb_fold_ws_elems(Cout, N, E), dtype=torch.float32, device=w.device)
+        call("mau_emb_fold_bwd", w.data_ptr(), e.data_ptr(), dweff.data_ptr(), dw.data_ptr() if dw is not None else None,
+             demb.data_ptr() if demb is not None else None, ws.data_ptr() if ws is not None else None, Cout, Ct, E, N, Ep, _stream())
+        return dw, demb, None, None
+
+
+_EMB_IDENTITY = {}
+_EMB_FOLD = os.environ.get("MAU_EMB_FOLD", "1") != "0"        # the broadcast embedding folded into roundup(N, 16) indicator channels (training)
+_EMB_FOLD_MIN_WORK = int(os.environ.get("MAU_EMB_FOLD_MIN_WORK", str(1 << 20)))      # batch x pixels from which folding pays
+
+
+def emb_identity(N: int, Ep: int, dev) -> torch.Tensor:
+    """The (N, Ep) identity "embedding" of a folded convolution (constant: cached per shape and device)."""
+    key = (N, Ep, str(dev))
+    t = _EMB_IDENTITY.get(key)
+    if t is None:
+        t = torch.zeros((N, Ep), dtype=torch.float32, device=dev)
+        t[torch.arange(N), torch.arange(N)] = 1.0
+        _EMB_IDENTITY[key] = t
+    return t
+
+
+def fold_embedding(weight: torch.Tensor, emb: torch.Tensor, Ct: int, pixels: int):
+    """(W_eff, identity embedding) if folding pays for this layer, else None: fewer 16-channel stages than the E broadcast channels,
+    and at least MAU_EMB_FOLD_MIN_WORK = 2^20 pixels in the batch.  What is saved grows with batch x pixels, what it costs -- deriving
+    and re-packing the weight every step, mapping its gradient back: five small launches per layer -- does not: measured on the
+    U-Net++ at B=16, folding the four full-resolution nodes takes 0.65 ms off the 19.8 ms step, the nodes below add nothing
+    (+-0.05 ms), and the U-Net's 16 x 16 bottleneck LOSES 0.2 ms.  Ep = roundup(N, 16), one more stage where that makes the stage
+    count even (the 16x16x32 multiply loop walks stage pairs)."""
+    N, E = emb.shape
+    Ep = (N + 15) // 16 * 16
+    if ((Ct + Ep) // 16) % 2 == 1 and Ct % 16 == 0:
+        Ep += 16
+    if not _EMB_FOLD or Ep + 16 > E or Ct % 8 != 0 or N * pixels < _EMB_FOLD_MIN_WORK:
+        return None
+    return EmbFold.apply(weight, emb, Ct, Ep), emb_identity(N, Ep, emb.device)
 
 
 class UpsampleTo(torch.autograd.Function):

@@ -77,16 +77,17 @@ class VGGBlock(nn.Module):
             self._frozen = [{}, {}]
 
     def _half(self, x: Act, emb, conv: nn.Conv2d, bn: nn.BatchNorm2d, x1: Optional[Act] = None, pool: bool = False, out_view=None,
-              head: Optional[nn.Conv2d] = None, head_act: bool = True, up_to=None):
+              head: Optional[nn.Conv2d] = None, head_act: bool = True, up_to=None, weight: Optional[torch.Tensor] = None):
         rt = self._rt or _Runtime()
-        if self._group is not None and getattr(conv.weight, "_mau_group", None) is not self._group:
+        if weight is None and self._group is not None and getattr(conv.weight, "_mau_group", None) is not self._group:
             self._group.add(conv.weight)          # (a deep copy of the network carries new Parameter objects)
         st = BNState(training=self.training and bn.training, C0=x.C, momentum=bn.momentum, eps=bn.eps,
                      group=rt.group, world=rt.world, grad_enabled=torch.is_grad_enabled(),
                      frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1],
                      C1=0 if x1 is None else x1.C, pool=pool, out_view=out_view,
                      head=None if head is None else bool(head_act), up_to=up_to)
-        t = F_.ConvBNReLU.apply(x.t, None if x1 is None else x1.t, emb, conv.weight, conv.bias, bn.weight, bn.bias,
+        # (``weight``: a tensor DERIVED from conv.weight that the convolution runs on instead -- functional.EmbFold's W_eff)
+        t = F_.ConvBNReLU.apply(x.t, None if x1 is None else x1.t, emb, conv.weight if weight is None else weight, conv.bias, bn.weight, bn.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 None if head is None else head.weight, None if head is None else head.bias, st)
         if head is not None:
@@ -95,6 +96,18 @@ class VGGBlock(nn.Module):
             return Act(t[0], conv.out_channels), Act(t[1], conv.out_channels)
         return Act(t, conv.out_channels)
 
+    def _fold(self, emb: Optional[torch.Tensor], Ct: int, pixels: int, dtype):
+        """Training: the broadcast embedding of conv1 folded into roundup(N, 16) indicator channels (functional.EmbFold) -- returns
+        (embedding the loader broadcasts, weight conv1 runs on).  Eval keeps the plain form: a frozen inference session caches packs
+        of the PARAMETERS, and the folded weight changes with every batch's embedding."""
+        # (16-bit modes only: fp32 is the parity mode and keeps the reference's association of the sums)
+        if emb is None or dtype == torch.float32 or not (self.training and torch.is_grad_enabled()):
+            return emb, None
+        folded = F_.fold_embedding(self.conv1.weight, emb, Ct, pixels)
+        if folded is None:
+            return emb, None
+        return folded[1], folded[0]
+
     def forward(self, x: Act, emb: Optional[torch.Tensor] = None, x1: Optional[Act] = None, pool: bool = False, out_view=None,
                 head: Optional[nn.Conv2d] = None, head_act: bool = True, up_to=None):
         """``x1``: second input tensor, channel-concatenated after ``x`` by the conv loader (never materialised);
@@ -102,7 +115,8 @@ class VGGBlock(nn.Module):
         output is written into (a slot of a U-Net++ row buffer); ``head``: the network's final 1x1 conv -- the block returns
         ``final(block output)`` (tanh on channel 0 when ``head_act`` and out_channels == 2) and the block output itself is never
         written; ``up_to=(H, W)``: the block returns the bilinear (align_corners=True) resize of its output instead of it."""
-        x = self._half(x, emb, self.conv1, self.bn1, x1)
+        emb, w1 = self._fold(emb, x.C + (0 if x1 is None else x1.C), x.H * x.W, x.t.dtype)
+        x = self._half(x, emb, self.conv1, self.bn1, x1, weight=w1)
         return self._half(x, None, self.conv2, self.bn2, None, pool, out_view, head, head_act, up_to)
 
 

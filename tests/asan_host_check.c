@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
   SYM(mau_bn_bwd_rows) SYM(mau_bcast_bwd_ws_elems) SYM(mau_head_bwd_rows) SYM(mau_head_bwd_rowlen) SYM(mau_mse_blocks)
   SYM(mau_l1_gradient_blocks) SYM(mau_lstm_bwd_ws_elems) SYM(mau_ssim_ws_elems) SYM(mau_lstm_max_hidden)
   SYM(mau_conv3x3_fwd) SYM(mau_conv3x3_fwd2) SYM(mau_conv3x3_wgrad2) SYM(mau_bn_relu_apply) SYM(mau_maxpool2x2_fwd)
-  SYM(mau_linear_fwd) SYM(mau_resize_bilinear_fwd) SYM(mau_head_fwd) SYM(mau_lstm_fwd) SYM(mau_ssim_loss) SYM(mau_nchw_to_nhwc) SYM(mau_copy_channels)
+  SYM(mau_linear_fwd) SYM(mau_resize_bilinear_fwd) SYM(mau_head_fwd) SYM(mau_lstm_fwd) SYM(mau_ssim_loss) SYM(mau_nchw_to_nhwc) SYM(mau_copy_channels) SYM(mau_emb_fold_fwd)
   if (p_mau_abi_version() != 2) return 5;
   size_t acc = 0;
   for (int dt = MAU_F32; dt <= MAU_F16; ++dt) {
@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
   REFUSED(p_mau_lstm_fwd(dummy, dummy, dummy, dummy, dummy, dummy, NULL, NULL, 1, 4, 200, NULL));                               /* H > 128 */
   REFUSED(p_mau_ssim_loss(dummy, dummy, (double*)dummy, dummy, dummy, 1, 1, 2, 8, 8, NULL));                                    /* smaller than the window */
   REFUSED(p_mau_nchw_to_nhwc(dummy, dummy, MAU_BF16, 1, 9, 2, 2, 8, NULL));                                                     /* ld < C */
+  REFUSED(p_mau_emb_fold_fwd((const float*)dummy, (const float*)dummy, (float*)dummy, 8, 16, 128, 32, 16, NULL));                             /* Ep < N */
   REFUSED(p_mau_copy_channels(dummy, 8, dummy, 8, 4, 0, MAU_BF16, 4, 8, NULL));                                                 /* choff + C > ld */
   printf("asan host check OK (%zu)\n", acc);
   return 0;

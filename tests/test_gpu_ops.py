@@ -590,3 +590,54 @@ def test_fused_bn_backward_matches_unfused(mau, model_type, size, base, prec, mo
         assert torch.equal(res[0][2][k], res[1][2][k]), k
     for k in res[0][3]:
         assert torch.equal(res[0][3][k], res[1][3][k]), k
+
+
+@pytest.mark.parametrize("N,Ep", [(3, 16), (16, 16), (5, 32)])
+def test_emb_fold_matches_its_definition(mau, N, Ep):
+    """functional.EmbFold (csrc/embfold.hip): W_eff = [W[:, :Ct] | W[:, Ct:] . emb^T] and its backward (dW, demb) against the same
+    contraction written with torch.einsum (fp32; sums of 128 / Cout * 9 terms: 1e-5 relative)."""
+    from mau_amd import functional as F_
+    g = torch.Generator().manual_seed(17)
+    Cout, Ct, E = 24, 40, 128
+    w = torch.randn(Cout, Ct + E, 3, 3, generator=g).cuda().requires_grad_(True)
+    emb = torch.randn(N, E, generator=g).cuda().requires_grad_(True)
+    gout = torch.randn(Cout, Ct + Ep, 3, 3, generator=g).cuda()
+    weff = F_.EmbFold.apply(w, emb, Ct, Ep)
+    weff.backward(gout)
+    w2, e2 = w.detach().clone().requires_grad_(True), emb.detach().clone().requires_grad_(True)
+    T = torch.einsum("oekl,ie->oikl", w2[:, Ct:], e2)
+    ref = torch.cat([w2[:, :Ct], T, torch.zeros(Cout, Ep - N, 3, 3, device="cuda")], dim=1)
+    ref.backward(gout)
+    assert rel_err(weff.detach(), ref.detach()) < 1e-5
+    assert rel_err(w.grad, w2.grad) < 1e-5 and rel_err(emb.grad, e2.grad) < 1e-5
+    assert float(weff[:, Ct + N:].abs().max()) == 0.0 if Ep > N else True
+
+
+@pytest.mark.parametrize("model_type,prec,tol", [("unet++", "fp32", 0.0), ("unet++", "bf16", 6e-2), ("unet++", "fp16", 2e-2)])
+def test_folded_embedding_trains_like_the_broadcast_one(mau, model_type, prec, tol, monkeypatch):
+    """MAU_EMB_FOLD: in training the E broadcast channels of a convolution run as roundup(N, 16) indicator channels with folded
+    weights (functional.fold_embedding).  Same function, re-associated sums: output, loss and every gradient of a step agree with the
+    plain form to rounding (16-bit: the yardstick of the other 16-bit tests); the fp32 parity mode does not fold: bit-identical."""
+    from mau_amd import functional as F_
+    flags = {} if model_type == "unet++" else dict(temporal_embeddings=True, metadata_embeddings=True)
+    g = torch.Generator().manual_seed(33)
+    x, ts, md = torch.randn(3, 6, 64, 48, generator=g).cuda(), torch.randn(3, 12, generator=g).cuda(), torch.randn(3, 4, generator=g).cuda()
+    tgt = torch.randn(3, 2, 64, 48, generator=g).cuda()
+    res = []
+    monkeypatch.setattr(F_, "_EMB_FOLD_MIN_WORK", 0)                  # (the test images are small: fold every layer that can be)
+    for fold in (True, False):
+        monkeypatch.setattr(F_, "_EMB_FOLD", fold)
+        torch.manual_seed(32)
+        net = mau.UrbanPredictor(model_type, 6, 12, 64, 4, 64, 24, 2, base_filters=16, **flags).cuda().set_precision(prec).train()
+        out = net(x, ts, md)
+        loss = mau.compute_loss_mse(out, tgt)["total"]
+        loss.backward()
+        res.append((out.detach().clone(), float(loss), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    assert res[0][2].keys() == res[1][2].keys()
+    if prec == "fp32":
+        assert torch.equal(res[0][0], res[1][0]) and all(torch.equal(res[0][2][k], res[1][2][k]) for k in res[0][2])
+        return
+    assert rel_err(res[0][0], res[1][0]) < tol and abs(res[0][1] - res[1][1]) < tol * abs(res[1][1])
+    num = sum(float(((res[0][2][k] - res[1][2][k]).double() ** 2).sum()) for k in res[0][2])
+    den = sum(float((res[1][2][k].double() ** 2).sum()) for k in res[0][2])
+    assert (num / den) ** 0.5 < 0.5, (num / den) ** 0.5
