@@ -237,6 +237,13 @@ int mau_head_bn_bwd_apply(const void* y, int ldy, const float* scale, const floa
                           const float* dout, void* dy, int lddy, int tanh0, int dtype, int N, int HW, int C, int Co,
                           mau_stream_t stream);
 
+/* dst = srcs[0] + srcs[1] + ... + srcs[k-1] (k <= mau_sum_tensors_max() NHWC-ld tensors of C channels, pixel pitches lds[i]; HOST
+ * arrays of k device pointers / pitches): the sum autograd forms when an activation has several readers (the row slots of the U-Net++,
+ * src/model.py:136-177), in one pass -- fp32 sums in the order given, one rounding. */
+int mau_sum_tensors_max(void);
+int mau_sum_tensors(const void* const* srcs, const int* lds, int k, void* dst, int lddst, int dtype, int64_t npix, int C,
+                    mau_stream_t stream);
+
 /* ---- the broadcast embedding of a convolution as a rank-one term (csrc/embfold.hip) ----
  * fuse_embeddings / the U-Net++ nodes' emb_map (src/model.py:248-259, :111-121) put E spatially constant channels behind the tensors a
  * 3x3 conv reads.  W_eff = [ W[:, :Ct] | T ], T[co][i][tap] = sum_e W[co][Ct+e][tap] * emb[i][e]  (Cout x (Ct+Ep) x 3 x 3, Ep >= N,

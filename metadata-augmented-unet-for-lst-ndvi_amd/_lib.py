@@ -92,6 +92,8 @@ PROTOTYPES = {
     "mau_adamw_pack_desc_bytes": (_sz, []),
     "mau_adamw_pack_desc_fill": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "mau_adamw_pack_step": (_i, [_p, _i, _i, _i, _p, _f, _f, _f, _f, _f, _p]),
+    "mau_sum_tensors_max": (_i, []),
+    "mau_sum_tensors": (_i, [_p, _p, _i, _p, _i, _i, _i64, _i, _p]),
     "mau_emb_fold_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mau_emb_fold_ws_elems": (_sz, [_i, _i, _i]),
     "mau_emb_fold_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

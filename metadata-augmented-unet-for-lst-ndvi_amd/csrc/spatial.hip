@@ -573,6 +573,40 @@ __global__ __launch_bounds__(256) void copy_channels_vec_kernel(const T* __restr
   }
 }
 
+// dst[p][c] = src_0[p][c] + src_1[p][c] + ... (k <= SUM_MAX_SRC NHWC-ld tensors, each with its own pixel pitch): the gradients an
+// activation with several readers receives (U-Net++ row slots, src/model.py:136-177).  One pass, fp32 sums in the order given, one
+// rounding -- instead of k - 1 generic strided torch adds (3 tensors of traffic each, a rounding per add).
+constexpr int SUM_MAX_SRC = 8;
+struct SumSrcs {
+  const void* p[SUM_MAX_SRC];
+  int ld[SUM_MAX_SRC];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void sum_tensors_kernel(SumSrcs srcs, int k, T* __restrict__ dst, int lddst, int64_t npix, int C8, int pixb) {
+  const int nv = C8 >> 3;
+  const int nvl = nv < 256 ? nv : 256, PS = 256 / nvl;
+  const int v = threadIdx.x % nvl, ps = threadIdx.x / nvl;
+  if (ps >= PS) return;
+  const int64_t p0 = (int64_t)blockIdx.x * pixb, p1 = p0 + pixb < npix ? p0 + pixb : npix;
+  for (int vv = v; vv < nv; vv += nvl) {
+    const int c = vv * 8;
+    for (int64_t pix = p0 + ps; pix < p1; pix += PS) {
+      F8 t[SUM_MAX_SRC];
+#pragma unroll
+      for (int i = 0; i < SUM_MAX_SRC; ++i)
+        if (i < k) t[i] = load8<T>(reinterpret_cast<const T*>(srcs.p[i]) + pix * srcs.ld[i] + c);
+      F8 acc = t[0];
+#pragma unroll
+      for (int i = 1; i < SUM_MAX_SRC; ++i)
+        if (i < k) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc.v[q] += t[i].v[q];
+        }
+      store8<T>(dst + pix * lddst + c, acc);
+    }
+  }
+}
+
 // dst[n, p, choff + e] = emb[n][e] for every pixel p (materialised broadcast; only used when the channel
 // counts do not fit the 8-channel granularity of the fused loader), then zero-fill up to zero_to
 template <typename T>
@@ -831,6 +865,25 @@ int mau_copy_channels(const void* src, int ldsrc, void* dst, int lddst, int chof
     MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(copy_channels_kernel<T>, dim3(grid), dim3(256), 0, st, (const T*)src, ldsrc, (T*)dst, lddst, choff, zero_to, npix, C));
   }
   return check_launch("copy_channels_kernel");
+}
+
+int mau_sum_tensors_max(void) { return SUM_MAX_SRC; }
+
+int mau_sum_tensors(const void* const* srcs, const int* lds, int k, void* dst, int lddst, int dtype, int64_t npix, int C,
+                    mau_stream_t stream) {
+  MAU_REQUIRE(srcs && lds && dst && k >= 1 && k <= SUM_MAX_SRC && npix > 0 && C > 0, "sum_tensors: 1..%d sources", SUM_MAX_SRC);
+  const int C8 = round_up(C, 8);
+  MAU_REQUIRE(lddst % 8 == 0 && lddst >= C8 && ((uintptr_t)dst % 16) == 0, "sum_tensors: bad destination ld / alignment");
+  SumSrcs a;
+  for (int i = 0; i < SUM_MAX_SRC; ++i) {
+    a.p[i] = i < k ? srcs[i] : srcs[0];
+    a.ld[i] = i < k ? lds[i] : lds[0];
+    MAU_REQUIRE(i >= k || (srcs[i] && lds[i] % 8 == 0 && lds[i] >= C8 && ((uintptr_t)srcs[i] % 16) == 0), "sum_tensors: bad source %d", i);
+  }
+  const int nv = C8 / 8, nvl = nv < 256 ? nv : 256;
+  const int pixb = (256 / nvl) * 8;
+  MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH(sum_tensors_kernel<T>, dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream, a, k, (T*)dst, lddst, npix, C8, pixb));
+  return check_launch("sum_tensors_kernel");
 }
 
 int mau_bcast_fill(const float* emb, void* dst, int lddst, int choff, int zero_to, int dtype, int N, int HW, int E,

@@ -812,6 +812,46 @@ class RowPrefix(torch.autograd.Function):
         return (None, *[g[..., j * ctx.C:(j + 1) * ctx.C] for j in range(ctx.k)])
 
 
+class Fanout(torch.autograd.Function):
+    """``Fanout.apply(x, k)`` -> k aliases of ``x``, one per reader.  Forward: views, no copy.  Backward: the readers' gradients
+    summed by ONE kernel (``mau_sum_tensors``: fp32 sums in reader order, one rounding) -- autograd's own accumulation of the
+    gradients of a shared activation is k - 1 generic strided ``at::add`` launches (the slices of the data-gradient buffers are
+    not contiguous), 3 tensors of traffic and a rounding each: 16 of them, 0.85 ms, in a U-Net++ step (src/model.py:136-177: every
+    row slot is read by the later nodes of its row and by the node above it)."""
+
+    @staticmethod
+    def forward(ctx, x, k: int):
+        ctx.k = k
+        ctx.meta = (x.shape, x.dtype, x.device)
+        return tuple(x.as_strided(x.shape, x.stride()) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes
+        shape, dtype, dev = ctx.meta
+        live = [_as_nhwc(g) for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        N, H, W, C = shape
+        ld = pad8(C)
+        kmax = lib.mau_sum_tensors_max()
+        out = torch.empty((N, H, W, ld), dtype=dtype, device=dev)
+        while True:                                          # (more readers than one launch takes: fold the first kmax, go on)
+            part = live[:kmax]
+            ptrs = (ctypes.c_void_p * len(part))(*[g.data_ptr() for g in part])
+            lds = (ctypes.c_int * len(part))(*[_ld(g) for g in part])
+            call("mau_sum_tensors", ctypes.addressof(ptrs), ctypes.addressof(lds), len(part), out.data_ptr(), ld, dtype_code(dtype),
+                 N * H * W, C, _stream())
+            live = [out] + live[kmax:]
+            if len(live) == 1:
+                break
+            out = torch.empty((N, H, W, ld), dtype=dtype, device=dev)
+        res = live[0]
+        return (res if ld == C else res[..., :C]), None
+
+
 class EmbFold(torch.autograd.Function):
     """The broadcast embedding of a 3x3 convolution as a rank-one term (csrc/embfold.hip).
 

@@ -641,3 +641,30 @@ def test_folded_embedding_trains_like_the_broadcast_one(mau, model_type, prec, t
     num = sum(float(((res[0][2][k] - res[1][2][k]).double() ** 2).sum()) for k in res[0][2])
     den = sum(float((res[1][2][k].double() ** 2).sum()) for k in res[0][2])
     assert (num / den) ** 0.5 < 0.5, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("k", [2, 5, 8, 11])
+def test_fanout_sums_the_readers_gradients_in_one_pass(mau, k, dt):
+    """functional.Fanout: k aliases of an activation (views, no copy); backward = mau_sum_tensors over the readers' gradients -- strided
+    slices of wider buffers included --: fp32 sums in reader order, ONE rounding (k <= 8; more readers are folded in groups of 8)."""
+    from mau_amd import functional as F_
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C = 2, 9, 7, 24
+    base = torch.randn(N, H, W, 2 * C, generator=g).cuda().to(dt)
+    x = base[..., C:].requires_grad_(False)                          # a slot of a wider buffer
+    x = x.detach().requires_grad_(True)
+    outs = F_.Fanout.apply(x, k)
+    assert all(o.data_ptr() == x.data_ptr() and o.shape == x.shape for o in outs)
+    grads = []
+    for i in range(k):
+        wide = torch.randn(N, H, W, 3 * C, generator=g).cuda().to(dt)
+        grads.append(wide[..., C:2 * C] if i % 2 == 0 else wide[..., :C].contiguous())
+    torch.autograd.backward(list(outs), grads)
+    ref = grads[0].float()
+    for t_ in grads[1:]:
+        ref = ref + t_.float()
+    if k <= 8:
+        assert torch.equal(x.grad, ref.to(dt))
+    else:
+        assert rel_err(x.grad.float(), ref) < (1e-6 if dt == torch.float32 else 1e-2)
