@@ -5,9 +5,17 @@
 
 A "step" is the inner training step of the reference (src/train.py:243-256) on one batch of
 synthetic input already resident in HBM: forward, MSE criterion, backward, AdamW step, zero_grad.
-On one GPU the step is captured once into a hipGraph (mau_amd.GraphedTrainStep; --no-graph = launched
-kernel by kernel from Python) and the K timed steps are K replays; under torch.distributed.run (N > 1)
-the step is eager, with the RCCL collectives overlapped from Python hooks.
+The step is captured once into a hipGraph (mau_amd.GraphedTrainStep; --no-graph = launched kernel by
+kernel from Python) and the K timed steps are K replays.  N > 1 (one rank per GPU): the captured step
+contains the RCCL collectives (SyncBN messages on the compute stream, gradient buckets on a
+communication stream).  A capture that misbehaves at N > 1 must not cost the measurement, so every
+rank runs under a SUPERVISOR that never touches the GPU: `python bench.py --gpus N` starts the N
+workers itself; under torch.distributed.run each launched rank is the supervisor of its own worker.
+Attempt 1 runs the workers with MAU_DP_GRAPH=1; a worker that exits non-zero or stops reporting
+progress is killed (with its process group) and a FRESH set of workers runs the eager step
+(MAU_DP_GRAPH=0) on a fresh rendezvous.  Nothing is ever exec'ed or restarted in place.
+The timed region (exactly K steps between barrier + synchronize) is repeated R times back to back
+(R chosen so the GPU phase lasts >= ~10 s) and the MEDIAN region is reported; the spread is in the line.
 Workload (BASELINE.json configs[1] / configs[3]): U-Net, base_filters 64, 6x256x256 tiles + 4-dim
 metadata, B = 32 per GPU, bf16 MFMA arithmetic with fp32 accumulation, fp32 master weights.
 Prints ONE JSON line on rank 0 (contract in the task description) carrying `roofline` (dominant
@@ -25,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+torch = None          # imported by main() in the process that does the work: a supervisor stays off torch and off the GPU
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_F32_TFLOPS = 157.3        # fp32 MFMA peak (same guide)
@@ -138,27 +146,164 @@ def cpu_baseline(iters=5, warmup=2):
                       f"train step (fwd+MSE+bwd+AdamW) {t_step:.2f} s, train-mode forward {t_fwd:.2f} s, eval forward {t_eval:.2f} s"}
 
 
-def self_launch(args, argv):
-    """``python bench.py --gpus N`` (N > 1) outside torch.distributed.run: start N ranks as CHILD processes -- this parent has
-    not touched the GPU and never execs -- relay rank 0's JSON line, and fail if any rank fails."""
+STAGE_TAG = "[mau-bench-stage]"
+# seconds without a NEW stage line before a worker counts as hung (stage it is in -> limit).  Generous where a slow host decides
+# (first `import torch` on a fresh box: 1-2 min; rendezvous waits for the slowest rank), tight where a broken capture would hang.
+STAGE_LIMITS = {"spawned": 420, "imported": 420, "ready": 240, "warm": 180, "captured": 180, "timed": 420, "done": 120}
+
+
+def stage(name):
+    """Progress line of a worker for its supervisor (stderr, so stdout stays the one JSON line)."""
+    if os.environ.get("MAU_BENCH_WORKER") == "1":
+        print(f"{STAGE_TAG} {name}", file=sys.stderr, flush=True)
+
+
+def _free_port():
     import socket
-    import subprocess
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-    for ln in proc.stdout.splitlines():
-        if ln not in lines:
-            print(ln, file=sys.stderr)
-    if proc.returncode != 0 or not lines:
-        raise SystemExit(proc.returncode or 1)
-    print(lines[-1], flush=True)
-    raise SystemExit(0)
+        return sock.getsockname()[1]
+
+
+def supervise_workers(cmds_envs, limits=None, poll=0.2, log=sys.stderr):
+    """Run one attempt: start every (cmd, env) as a child in its own session, relay their stderr, watch their stage lines.
+    Returns (ok, stdout of worker 0).  ok = every worker reported `done` (after which its exit code no longer matters:
+    the result line is out and the ranks have passed their last barrier) or exited 0.  On the first failure -- a non-zero
+    exit before `done`, or no new stage line within the stage's limit -- ALL workers of the attempt are killed (SIGKILL to
+    their sessions: a rank hung in a collective ignores anything gentler)."""
+    import signal
+    import subprocess
+    import threading
+    limits = dict(STAGE_LIMITS, **(limits or {}))
+    scale = float(os.environ.get("MAU_BENCH_STALL_SCALE", "1"))
+    procs, state = [], []
+
+    def pump(i, pipe):
+        for line in pipe:
+            if line.startswith(STAGE_TAG):
+                state[i]["stage"] = line[len(STAGE_TAG):].strip()
+                state[i]["t"] = time.monotonic()
+            else:
+                log.write(line)
+                log.flush()
+
+    for i, (cmd, env) in enumerate(cmds_envs):
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        procs.append(p)
+        state.append({"stage": "spawned", "t": time.monotonic(), "out": []})
+        threading.Thread(target=pump, args=(i, p.stderr), daemon=True).start()
+        threading.Thread(target=lambda i=i, p=p: state[i]["out"].extend(p.stdout), daemon=True).start()
+    failure = None
+    while failure is None:
+        alive = False
+        for i, p in enumerate(procs):
+            rc = p.poll()
+            st = state[i]
+            if rc is None:
+                alive = True
+                if time.monotonic() - st["t"] > limits.get(st["stage"], 240) * scale:
+                    if st["stage"] == "done":             # result out, last barrier passed: a rank stuck in its teardown is just ended
+                        try:
+                            os.killpg(p.pid, signal.SIGKILL)
+                        except (ProcessLookupError, PermissionError):
+                            pass
+                        continue
+                    failure = f"worker {i} made no progress for {limits.get(st['stage'], 240) * scale:.0f} s in stage '{st['stage']}'"
+            elif rc != 0 and st["stage"] != "done":
+                failure = f"worker {i} exited with code {rc} in stage '{st['stage']}'"
+        if not alive:
+            break
+        time.sleep(poll)
+    if failure is not None:
+        print(f"bench.py supervisor: {failure}; killing this attempt's workers", file=log, flush=True)
+    for p in procs:                                   # (also after success: nothing of the attempt may linger)
+        if p.poll() is None and failure is not None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except Exception:
+            pass
+    time.sleep(0.2)                                   # let the stdout reader threads drain
+    return failure is None, "".join(state[0]["out"]) if state else ""
+
+
+def run_supervised(make_attempt, log=sys.stderr):
+    """Attempt 1: captured data-parallel step (MAU_DP_GRAPH=1) unless the environment pins the mode; attempt 2 (only after a
+    failed attempt 1): eager step, fresh workers, fresh rendezvous.  ``make_attempt(k, dp_graph)`` -> list of (cmd, env).
+    Prints the surviving attempt's JSON line; exit code 0 iff one attempt succeeded."""
+    pinned = os.environ.get("MAU_DP_GRAPH")
+    plan = [pinned == "1"] if pinned in ("0", "1") else [True, False]
+    for k, dp_graph in enumerate(plan):
+        ok, out = supervise_workers(make_attempt(k, dp_graph), log=log)
+        lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        for ln in out.splitlines():
+            if ln not in lines:
+                print(ln, file=log)
+        if ok:
+            if lines:
+                print(lines[-1], flush=True)
+            return 0
+        if k + 1 < len(plan):
+            print("bench.py supervisor: falling back to the eager data-parallel step with fresh workers", file=log, flush=True)
+    return 1
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` (N > 1) outside torch.distributed.run: this process -- it has not touched the GPU and never
+    execs -- is the supervisor of all N ranks."""
+    def make_attempt(k, dp_graph):
+        port = _free_port()
+        out = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), MAU_BENCH_WORKER="1", MAU_DP_GRAPH="1" if dp_graph else "0")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+            out.append(([sys.executable, os.path.abspath(__file__)] + argv, env))
+        return out
+
+    raise SystemExit(run_supervised(make_attempt))
+
+
+def _agree_on_port(attempt: int, timeout: float = 120.0) -> int:
+    """A fresh rendezvous port for one attempt's workers, agreed between the rank supervisors of ONE node without a collective:
+    the supervisor of local rank 0 picks a free port and publishes it in a file named after the launcher's pid (the parent of
+    every rank it started) and the attempt; the others wait for the file.  The launcher's own store is not used for the
+    workers: it has no per-attempt key space, so the addresses a failed attempt left there would poison the next one."""
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"mau_bench_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{attempt}.port")
+    if int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))) == 0:
+        port = _free_port()
+        with open(path + ".tmp", "w") as f:
+            f.write(str(port))
+        os.replace(path + ".tmp", path)
+        return port
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < timeout:
+        try:
+            with open(path) as f:
+                return int(f.read())
+        except (OSError, ValueError):
+            time.sleep(0.05)
+    raise SystemExit(f"bench.py supervisor: rank 0's supervisor never published the port of attempt {attempt} ({path})")
+
+
+def rank_supervisor(argv):
+    """Under torch.distributed.run (RANK / WORLD_SIZE set by the launcher): this launched process stays off the GPU and supervises
+    ONE worker -- its rank.  Every rank's supervisor applies the same rule, so a failed attempt 1 ends on every rank (a rank
+    that lost a peer hangs in its next collective and is killed at the stage limit) and attempt 2's workers meet on a fresh
+    rendezvous (rank 0 of the workers hosts a store on a port of the attempt's own, ``_agree_on_port``)."""
+    def make_attempt(k, dp_graph):
+        env = dict(os.environ, MAU_BENCH_WORKER="1", MAU_DP_GRAPH="1" if dp_graph else "0", MASTER_PORT=str(_agree_on_port(k)))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        # (MAU_BENCH_WORKER_SCRIPT: the CPU tests put a stand-in for the GPU worker here)
+        return [([sys.executable, os.environ.get("MAU_BENCH_WORKER_SCRIPT") or os.path.abspath(__file__)] + argv, env)]
+
+    raise SystemExit(run_supervised(make_attempt))
 
 
 def workload_key(args):
@@ -191,10 +336,25 @@ def main():
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass; default: the "
                          "figure committed under profiles/ for the same workload (profiles/r2/pmc_summary.json)")
+    ap.add_argument("--repeats", type=int, default=0, help="how many times the K-step timed region is run back to back (median reported); "
+                                                           "0 = as many as make the GPU phase last about 10 s")
     args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args, sys.argv[1:])           # before anything touches the GPU
+    if os.environ.get("MAU_BENCH_WORKER") != "1":
+        # supervisors: before anything touches the GPU (or even imports torch)
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            self_launch(args, sys.argv[1:])
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            rank_supervisor(sys.argv[1:])
+    stage("spawned")
+    global torch
+    import torch
+    stage("imported")
+    # the CPU baseline runs FIRST (rank 0, N = 1): the GPU phase that follows is then one contiguous stretch of the run
+    cpu_rec = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu_rec = cpu_baseline()
 
+    os.environ.setdefault("MAU_QUIET", "1")        # stdout carries the one JSON line: the constructor's announcement stays off it
     import mau_amd
     from mau_amd import functional as F_
     from mau_amd.dist import GradSync, init_process_group_from_env
@@ -244,7 +404,8 @@ def main():
             net(x, ts, md)
 
     graphed = None
-    # data parallel: eager by default (the collectives are launched from autograd hooks); MAU_DP_GRAPH=1 captures them too
+    # data parallel: MAU_DP_GRAPH=1 captures the step with its collectives (the supervisor's first attempt); 0 = eager, the
+    # collectives launched from autograd hooks (the supervisor's fallback, and the default of an unsupervised worker)
     dp_graph = sync is not None and os.environ.get("MAU_DP_GRAPH", "0") == "1"
     if not args.infer and not args.no_graph and ((world == 1 and sync is None) or dp_graph):
         criterion = lambda o, t: mau_amd.compute_loss_mse(o, t)          # noqa: E731  (src/train.py:218-219)
@@ -253,6 +414,7 @@ def main():
     def step(i):
         if args.infer:
             return infer_step(i)
+        i %= losses.numel()
         if graphed is not None:                       # fwd + MSE + bwd + AdamW step: eager while warming up, then one graph replay
             losses[i] = graphed(x, ts, md, tgt)
             return
@@ -269,7 +431,7 @@ def main():
 
     if args.infer:
         net.eval().freeze_inference()      # inference session: packed weights / folded BN coefficients computed once
-        if world == 1 and not args.no_graph:
+        if not args.no_graph:          # (N > 1: every rank is an independent replica with a session of its own, no collective)
             session[0] = mau_amd.GraphedInference(net, x, ts, md)
     timer = ConvTimer(F_)
     timer.install()
@@ -279,13 +441,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    stage("ready")
     try:
         for i in range(args.warmup):
             step(i)
+            if graphed is not None and i + 1 == graphed.warmup:
+                torch.cuda.synchronize()
+                stage("warm")                                 # the next call captures
         if graphed is not None and graphed.graph is None:     # fewer warm-up steps than the capture needs: capture before the clock starts
             for i in range(graphed.warmup + 1 - args.warmup):
                 step(0)
     except RuntimeError as e:
+        # N > 1: no in-rank recovery -- the worker fails, its supervisor starts a fresh eager set (a child spawned from here would
+        # inherit a rendezvous the other ranks still hold)
+        if world > 1 and graphed is not None:
+            # leave at once, skipping every teardown (a process group whose peers are mid-collective, a half-built graph): the
+            # supervisor sees the exit code and starts the eager set
+            print(f"bench.py worker (rank {rank}): {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            os._exit(17)
         if graphed is None or "capturing the train step failed" not in str(e):
             raise
         # A broken capture leaves this process's stream state untrustworthy: run the eager bench in a CHILD process (never an
@@ -296,17 +469,51 @@ def main():
         sys.stdout.write(proc.stdout)
         raise SystemExit(proc.returncode)
     barrier()
+    stage("captured")
     # per-kernel events inside the timed region only when every kernel has the GPU to itself there: not under a graph replay (no
     # events in a graph) and not with the weight gradients on their own stream (two kernels share the chip: neither's events
     # measure it alone) -- then the same K steps are launched again afterwards, eagerly, on one stream, with the brackets
-    separate_pass = session[0] is not None if args.infer else (graphed is not None or (F_._OVERLAP_WGRAD and sync is None))
+    separate_pass = session[0] is not None if args.infer else (graphed is not None or bool(F_._OVERLAP_WGRAD))
     timer.enabled = not separate_pass
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
+
+    def max_over_ranks(vals):
+        if world == 1:
+            return list(vals)
+        tt = torch.tensor(list(vals), dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return tt.tolist()
+
+    def timed_region():
+        """EXACTLY K steps between barrier + synchronize on both sides (the contract's timed region)."""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        barrier()
+        return time.perf_counter() - t0
+
+    regions = [timed_region()]
+    repeats = args.repeats
+    if repeats <= 0:      # ~10 s of contiguous GPU work, the same count on every rank (derived from the max-over-ranks first region)
+        repeats = max(1, min(100, int(10.0 / max(1e-3, max_over_ranks(regions)[0]) + 0.5)))
+    timer.enabled = False                                    # (events of the first region only)
+    for _ in range(repeats - 1):
+        regions.append(timed_region())
+    regions = max_over_ranks(regions)                        # per region: the slowest rank's clock
+    elapsed = statistics.median(regions)
+    # the reference loop reads the loss back every step (src/train.py:258, `.detach().cpu().item()`): the same K steps with that
+    # read-back (one host synchronisation per step) -- reported beside the headline figure, not instead of it
+    readback_ms = None
+    if not args.infer:
+        barrier()
+        t0 = time.perf_counter()
+        acc = 0.0
+        for i in range(args.steps):
+            step(args.warmup + i)
+            acc += float(losses[(args.warmup + i) % losses.numel()])
+        barrier()
+        readback_ms = max_over_ranks([time.perf_counter() - t0])[0] / args.steps * 1e3
+    stage("timed")
     timing_pass = "HIP events on the launch stream around every launch, inside the timed region"
     if separate_pass:
         # the same K steps launched eagerly (kernel by kernel, same resident batch, same kernels, ONE stream) right after the timed
@@ -333,10 +540,6 @@ def main():
         F_._OVERLAP_WGRAD = overlap
         timing_pass = (f"HIP events on the launch stream around every launch over {args.steps} eager steps of the same workload run "
                        "on one stream right after the timed region (the timed steps are hipGraph replays / run the weight gradients on a second stream)")
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
 
     # ---- forward latency per tile (eval mode, no_grad), outside the timed region -----------------
     net.eval()
@@ -352,11 +555,15 @@ def main():
         fwd_ms_per_tile = (time.perf_counter() - t1) / nf / B * 1e3
     net.train()
 
-    if rank != 0:
+    def finish():
         if world > 1:
-            dist.barrier()
+            dist.barrier()                 # every rank is through its work: from here on an exit code cannot cost the measurement
+        stage("done")
+        if world > 1:
             dist.destroy_process_group()
-        return
+
+    if rank != 0:
+        return finish()
 
     conv = timer.summary()
     wg = timer.wgrad_summary()
@@ -365,19 +572,32 @@ def main():
     wkey = workload_key(args)
     traffic, traffic_src, rec = args.traffic_bytes, "--traffic-bytes", {}
     if traffic is None:
-        for rnd in ("r3", "r2"):
+        # The counters describe the LIBRARY they were measured on: the summary carries the sha256 of libmau_hip.so, and figures of
+        # another binary are not quoted (traffic: null + the reason) -- a kernel change without a re-profile cannot go stale silently.
+        import hashlib
+        from mau_amd import _lib
+        with open(_lib.LIB_PATH, "rb") as f:
+            lib_sha = hashlib.sha256(f.read()).hexdigest()
+        traffic_src = "no PMC record of this workload under profiles/"
+        for rnd in ("r4", "r3", "r2"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
-                    rec = json.load(f)[wkey]
-                traffic = rec["hbm_bytes_per_launch"]
-                traffic_src = f"profiles/{rnd}/pmc_summary.json[{wkey}]: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"
-                break
+                    cand = json.load(f)[wkey]
             except (OSError, KeyError, ValueError):
-                traffic, rec = None, {}
+                continue
+            if cand.get("lib_sha256") != lib_sha:
+                traffic_src = (f"profiles/{rnd}/pmc_summary.json[{wkey}] was measured on another build of libmau_hip.so "
+                               f"(sha256 {str(cand.get('lib_sha256'))[:12]} vs loaded {lib_sha[:12]}): not quoted; re-run scripts/profile.sh")
+                break
+            rec = cand
+            traffic = rec["hbm_bytes_per_launch"]
+            traffic_src = (f"profiles/{rnd}/pmc_summary.json[{wkey}] (same libmau_hip.so, sha256 {lib_sha[:12]}): "
+                           "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes")
+            break
     peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same rate
     achieved = conv["total_flop"] / (conv["total_ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "conv3x3_bf16_kernel (forward + data-gradient launches)",
                 "launches": conv["launches"], "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
                 "flop_per_launch_avg": conv["total_flop"] / conv["launches"],
@@ -405,6 +625,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "timed_regions": {"repeats": len(regions), "reported": "median region (each region: exactly K steps between barrier + synchronize, max over ranks)",
+                          "ms_per_step_min": round(min(regions) / args.steps * 1e3, 3), "ms_per_step_max": round(max(regions) / args.steps * 1e3, 3),
+                          "ms_per_step_first": round(regions[0] / args.steps * 1e3, 3)},
+        "ms_per_step_with_loss_readback": None if readback_ms is None else round(readback_ms, 3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -414,7 +638,9 @@ def main():
                                 + (f"temperature series of {args.seq_len} months, " if (args.seq_len != 10 or args.temporal_embeddings) else "")
                                 + ("eval-mode forward only (inference)" if args.infer else "fwd+MSE+bwd+AdamW (src/train.py:243-256)")),
                    "global_batch": B * world, "parallelism": f"dp{world}" + (" (data-parallel path forced under a 1-rank RCCL group)" if args.force_dist and world == 1 else ""),
-                   "sync_bn": bool(world > 1 and not args.no_sync_bn),
+                   "sync_bn": bool(sync is not None and not args.no_sync_bn),
+                   "collectives": (None if sync is None else "RCCL called directly (ncclAllReduce on the compute / communication stream)"
+                                   if sync.comm is not None else f"torch.distributed ({dist.get_backend()})"),
                    "launch": ("hipGraph replay of the captured step" if graphed is not None else
                               "hipGraph replay (GraphedInference session: input copies + replay + output clone per call)" if session[0] is not None
                               else "eager (kernel by kernel)")},
@@ -423,12 +649,10 @@ def main():
         "final_loss": float(losses[-1]),
         "roofline": roofline,
     }
-    if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
+    if cpu_rec is not None:
+        result["cpu_baseline"] = cpu_rec
     print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish()
 
 
 if __name__ == "__main__":

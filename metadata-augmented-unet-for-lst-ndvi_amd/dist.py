@@ -1,34 +1,152 @@
-"""Data-parallel training support: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL
-over xGMI on ROCm; "gloo" in the CPU tests).
+"""Data-parallel training support: one process per GPU, RCCL over xGMI ("gloo" in the CPU tests).
 
 The reference has no multi-GPU code at all; this is new behaviour with reference
 semantics: N ranks x per-rank batch b with synchronised BatchNorm statistics and averaged gradients
 equals the reference on one device with batch N*b.
 
-Two collectives per step family:
-  * gradients: all parameters' gradients live in ONE flat fp32 arena; it is cut into buckets in
-    reverse registration order (= backward arrival order) and each bucket is all-reduced
-    asynchronously as soon as its last gradient has arrived, overlapping the rest of backward.
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages (default 32 MiB) keep
-    every link busy; tiny per-tensor messages would be latency-bound.  The convolution weight
-    gradients (99.9 % of the bytes) are WRITTEN INTO the arena by the kernel that produces them
-    (``functional.ConvBNReLU.backward`` unpacks the split-K sum straight into the parameter's arena slot and
-    autograd adopts that view as ``p.grad``: no copy); the few small tensors left enter through one
-    multi-tensor copy per bucket.  The collective averages (ReduceOp.AVG on RCCL).
-  * BatchNorm: per layer one all-reduce of [sum | sum of squares] (2C fp64) in forward and one of
-    [sum dz | sum dz*xhat] in backward -- see ``functional.ConvBNReLU``; enabled by
-    ``model.set_sync_bn(group)``.
+How the collectives are issued (round 4).  ``torch.distributed`` is the rendezvous (ranks, store, barrier); the
+data-path collectives are **direct ``ncclAllReduce`` calls into librccl on the stream we name** (``RcclComm``, a ctypes
+binding of the RCCL that torch itself ships), not ``ProcessGroupNCCL`` calls.  ProcessGroupNCCL runs every collective on
+ITS OWN stream: each call is an event hand-over there and back (the waiting kernel sits behind two events), a Work object, a
+watchdog entry -- 30-40 us of host time and two stream switches, 36 times per step for the latency-bound BatchNorm messages;
+and all collectives of a group are serialised on that one stream, so a 0.5-16 KB BatchNorm message that the backward
+pass is waiting for queues behind a 32 MiB gradient bucket issued before it.  Here:
+  * **SyncBN** (18 forward + 18 backward messages of [sums | pixel count], 2C+1 fp64): ``ncclAllReduce`` on the COMPUTE
+    stream itself, between the kernel that produces the sums and the one that consumes them -- stream order is the only
+    synchronisation, no events, and under hipGraph capture the collective is just one more kernel node.  (The backward
+    sums cannot ride with the gradient buckets, as round 3's notes hoped: BatchNorm's backward needs the GLOBAL
+    sum(dz), sum(dz*xhat) before it can form dz of that layer -- the very next kernel.)
+  * **gradients**: all parameters' gradients live in ONE flat fp32 arena cut into ~32 MiB buckets in reverse registration
+    order (= backward arrival order); when a bucket's last gradient arrives its all-reduce (``ncclAvg``) is issued on a
+    COMMUNICATION stream through a SECOND communicator: that stream waits (events) for the streams that produced the
+    bucket's gradients -- the compute stream and the weight-gradient side stream -- and the compute stream never waits for
+    anything until ``finish()``, one join per step.  The weight-gradient side stream therefore stays ON under data parallelism
+    (round 3 switched it off: every bucket launch made the main stream wait for it).  xGMI is point-to-point
+    (7 links x ~153 GB/s per GPU): few large messages keep every link busy.  The convolution weight gradients
+    (99.9 % of the bytes) are WRITTEN INTO the arena by the kernel that produces them; the few small tensors enter
+    through one multi-tensor copy per bucket.
+Under the "gloo" backend (CPU tests; several ranks sharing one GPU in the rehearsals) there is no RCCL communicator:
+the same messages go through ``torch.distributed`` (device tensors staged through host memory) -- correctness rehearsal,
+never the measured path.
 
 Parameters that receive no gradient (``temporal_encoder.*`` when ``temporal_embeddings=False``,
 SURVEY D4) keep ``grad is None`` exactly as in the reference; their arena slots stay zero.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 import weakref
 from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
+
+# --------------------------------------------------------------------------- #
+# librccl, called directly (rccl.h: ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy)
+# --------------------------------------------------------------------------- #
+NCCL_SUM, NCCL_AVG = 0, 4                      # ncclRedOp_t
+_NCCL_DTYPE = {torch.float32: 7, torch.float64: 8, torch.bfloat16: 9, torch.float16: 6, torch.int32: 2, torch.int64: 4}
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]              # NCCL_UNIQUE_ID_BYTES
+
+
+_RCCL = [None]
+
+
+def _rccl():
+    """The RCCL torch was built with (``torch/lib/librccl.so``: already mapped into the process, so this adds no second
+    copy of the library), else the ROCm installation's."""
+    if _RCCL[0] is None:
+        cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "librccl.so.1", "librccl.so"]
+        err = None
+        for path in cands:
+            try:
+                lib = C.CDLL(path)
+                break
+            except OSError as e:
+                err = e
+        else:
+            raise ImportError(f"librccl not found ({err}); data-parallel runs over RCCL need it")
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclGetErrorString.argtypes = [C.c_int]
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclCommAbort.argtypes = [C.c_void_p]
+        _RCCL[0] = lib
+    return _RCCL[0]
+
+
+def _nccl_check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"RCCL {what} failed: {_rccl().ncclGetErrorString(status).decode()} (ncclResult_t {status})")
+
+
+class RcclComm:
+    """One RCCL communicator over the ranks of a ``torch.distributed`` group (which is used ONLY to hand rank 0's
+    ``ncclUniqueId`` to the others).  ``all_reduce`` enqueues ``ncclAllReduce`` on the stream it is given and returns:
+    ordering against kernels is stream order, exactly like a kernel launch through the C ABI.  Collectives of ONE communicator
+    must be issued in the same order on every rank and on one stream at a time -- SyncBN (compute stream) and the gradient
+    buckets (communication stream) therefore own a communicator each."""
+
+    def __init__(self, group=None, device: Optional[torch.device] = None):
+        group = group if group is not None else dist.group.WORLD
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        lib = _rccl()
+        uid = _UniqueId()
+        if self.rank == 0:
+            _nccl_check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        if self.world > 1:
+            box = [bytes(uid.internal)] if self.rank == 0 else [None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0), group=group,
+                                       device=self.device if dist.get_backend(group) == "nccl" else None)
+            C.memmove(C.byref(uid), box[0], 128)
+        self._comm = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _nccl_check(lib.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self._fin = weakref.finalize(self, RcclComm._destroy, self._comm.value)
+
+    @staticmethod
+    def _destroy(handle):
+        try:
+            _rccl().ncclCommDestroy(C.c_void_p(handle))
+        except Exception:            # interpreter shutdown: the runtime may already be gone
+            pass
+
+    def all_reduce(self, t: torch.Tensor, op: int = NCCL_SUM, stream: Optional[int] = None):
+        """In-place all-reduce of a contiguous device tensor on ``stream`` (a raw ``hipStream_t``; default: torch's current)."""
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("RcclComm.all_reduce needs a contiguous device tensor")
+        if stream is None:
+            stream = torch.cuda.current_stream(t.device).cuda_stream
+        _nccl_check(_rccl().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _NCCL_DTYPE[t.dtype], op, self._comm, stream),
+                    "ncclAllReduce")
+
+    def destroy(self):
+        self._fin()
+
+
+_COMMS = {}
+
+
+def rccl_comm(group, tag: str) -> Optional[RcclComm]:
+    """The process's communicator ``tag`` ("bn" / "grad") over ``group``, created on first use by EVERY rank of the group
+    (creation is itself a collective); ``None`` when the group does not run on RCCL (gloo rehearsals, CPU tests) or
+    ``MAU_RCCL_DIRECT=0`` (A/B switch: everything through ProcessGroupNCCL, as in round 3)."""
+    if group is None or not torch.cuda.is_available() or dist.get_backend(group) != "nccl":
+        return None
+    if os.environ.get("MAU_RCCL_DIRECT", "1") == "0":
+        return None
+    key = (id(group), tag, torch.cuda.current_device())
+    c = _COMMS.get(key)
+    if c is None:
+        c = _COMMS[key] = RcclComm(group)
+    return c
 
 
 def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
@@ -44,7 +162,7 @@ def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
 
 
 class _Bucket:
-    __slots__ = ("lo", "hi", "params", "pending", "handle", "launched", "streams")
+    __slots__ = ("lo", "hi", "params", "pending", "handle", "launched", "streams", "side_streams")
 
     def __init__(self):
         self.lo = self.hi = 0
@@ -52,12 +170,8 @@ class _Bucket:
         self.pending = 0
         self.handle = None
         self.launched = False
-        self.streams = []
-
-
-def _grad_sync_gone():
-    from . import functional as F_
-    F_._GRAD_SYNC_ACTIVE[0] -= 1
+        self.streams = []            # streams on which autograd accumulated a gradient of the bucket (the backward nodes' streams)
+        self.side_streams = []       # weight-gradient streams still WRITING arena slots of the bucket (functional: deferred join)
 
 
 class GradSync:
@@ -101,11 +215,11 @@ class GradSync:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._active = False
         self._avg = self.group is not None and dist.get_backend(self.group) == "nccl"
-        self._counted = None
-        if self.group is not None:
-            from . import functional as F_
-            F_._GRAD_SYNC_ACTIVE[0] += 1          # (the weight-gradient side stream stays off while buckets are launched inside backward)
-            self._counted = weakref.finalize(self, _grad_sync_gone)      # remove() or garbage collection, whichever comes first
+        # RCCL called directly on a communication stream of our own (module docstring); None = through torch.distributed
+        self.comm = rccl_comm(self.group, "grad") if dev.type == "cuda" else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.comm is not None else None
+        self._comm_used = False
+        self._dirty = set()           # ids of parameters whose arena slot has held a gradient (the arena starts zeroed)
 
     # ------------------------------------------------------------------ #
     def begin(self):
@@ -114,17 +228,22 @@ class GradSync:
             b.handle = None
             b.launched = False
             b.streams = []
+            b.side_streams = []
         self._active = True
+        self._comm_used = False
 
     def _launch(self, b: _Bucket):
-        """All gradients of the bucket have arrived: move them into the arena with ONE multi-tensor copy (instead of a
-        small kernel per parameter), re-point ``p.grad`` at the arena slots, start the bucket's all-reduce."""
+        """All gradients of the bucket have arrived: move the small ones into the arena with ONE multi-tensor copy (the
+        convolution weights' are born there), re-point ``p.grad`` at the arena slots, start the bucket's all-reduce."""
         b.launched = True
-        if b.streams:
-            # gradients of this bucket were produced on other streams too (the TemporalEncoder's backward runs on its side
-            # stream): the launching stream waits for them before the copy / the collective read the arena
-            cur = torch.cuda.current_stream()
-            for s in b.streams:
+        cur = torch.cuda.current_stream() if self.flat.is_cuda else None
+        # gradients accumulated on other streams (the TemporalEncoder's backward runs on its side stream): the launching stream
+        # waits for those before the copy reads them
+        for s in b.streams:
+            if s != cur:
+                cur.wait_stream(s)
+        if self.comm is None:                          # torch.distributed issues the collective behind the launching stream:
+            for s in b.side_streams:                   # that stream must have seen the weight-gradient streams' writes too
                 if s != cur:
                     cur.wait_stream(s)
         have = [p for p in b.params if p.grad is not None and p.grad.data_ptr() != p._mau_grad_slot.data_ptr()]
@@ -133,41 +252,57 @@ class GradSync:
             torch._foreach_copy_(views, [p.grad for p in have])
             for p, v in zip(have, views):
                 p.grad = v
-        if self.group is not None:
-            seg = self.flat[b.lo:b.hi]
-            if self._avg:                                  # RCCL averages in the collective itself
-                b.handle = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            else:                                          # gloo has no AVG: pre-scale, then SUM
-                seg.mul_(1.0 / self.world)
-                b.handle = all_reduce_sum(seg, self.group, async_op=True)
+        if self.group is None:
+            return
+        seg = self.flat[b.lo:b.hi]
+        if self.comm is not None:
+            # the COMMUNICATION stream waits for the launching stream (which has joined every accumulation stream and ran the
+            # copy) and for the weight-gradient streams still writing slots of this bucket; the compute stream just goes on
+            cs = self.comm_stream
+            cs.wait_stream(cur)
+            for s in b.side_streams:
+                if s != cur:
+                    cs.wait_stream(s)
+            self.comm.all_reduce(seg, NCCL_AVG, cs.cuda_stream)
+            self._comm_used = True
+        elif self._avg:                                # ProcessGroupNCCL (MAU_RCCL_DIRECT=0): averages in the collective itself
+            b.handle = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        else:                                          # gloo has no AVG: pre-scale, then SUM
+            seg.mul_(1.0 / self.world)
+            b.handle = all_reduce_sum(seg, self.group, async_op=True)
 
     def _on_grad(self, p: torch.nn.Parameter):
         if not self._active:
             return
         b = self._slot[id(p)][2]
+        self._dirty.add(id(p))
         if p.is_cuda:
             s = torch.cuda.current_stream(p.device)
             if s not in b.streams:
                 b.streams.append(s)
             ws = getattr(p, "_mau_grad_stream", None)       # the gradient is still being written on the weight-gradient stream
-            if ws is not None and ws not in b.streams:
-                b.streams.append(ws)
+            if ws is not None and ws not in b.side_streams:
+                b.side_streams.append(ws)
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
 
     def finish(self):
-        """Launch what is left (buckets holding never-used parameters), then wait for everything."""
+        """Launch what is left (buckets holding never-used parameters), then make the caller's stream wait for everything."""
         if not self._active:
             return
         for b in self.buckets:
             if not b.launched:
-                # slots of parameters without a gradient this step must not carry stale values
+                # slots of parameters without a gradient this step must not carry stale values (a slot that never held a
+                # gradient is still zero: no fill kernel per step for the parameters that are never used, SURVEY D4)
                 for p in b.params:
-                    if p.grad is None:
+                    if p.grad is None and id(p) in self._dirty:
                         lo, hi, _ = self._slot[id(p)]
                         self.flat[lo:hi].zero_()
+                        self._dirty.discard(id(p))
                 self._launch(b)
+        if self._comm_used:                           # ONE join per step: the optimizer reads the averaged arena
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
         for b in self.buckets:
             if b.handle is not None:
                 b.handle.wait()
@@ -178,9 +313,6 @@ class GradSync:
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        if self._counted is not None:
-            self._counted()                       # (a finalizer runs once)
-            self._counted = None
         for p in self.params:
             if hasattr(p, "_mau_grad_slot"):
                 del p._mau_grad_slot

@@ -291,6 +291,7 @@ class BNState:
     momentum: float = BN_MOMENTUM
     eps: float = BN_EPS
     group: object = None                  # torch.distributed process group for SyncBN (None = local BN)
+    comm: object = None                   # dist.RcclComm of that group (RCCL called directly on the compute stream) or None
     world: int = 1
     grad_enabled: bool = True             # torch.is_grad_enabled() at call time (invisible inside Function.forward)
     frozen: object = None                 # dict of a frozen inference session (packed weights, scale, shift) or None
@@ -302,7 +303,13 @@ class BNState:
 
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
-    if st.group is not None:               # an explicitly given group is used even when it has one rank
+    """SUM all-reduce of a BatchNorm message, in place, ordered on the CURRENT stream between the kernel that wrote ``t`` and the one
+    that reads it.  ``st.comm`` (dist.RcclComm, set by ``model.set_sync_bn``): ``ncclAllReduce`` enqueued on this very stream -- no
+    stream hand-over, no host wait, a plain kernel node under graph capture.  Without a communicator (gloo rehearsal / CPU tests,
+    ``MAU_RCCL_DIRECT=0``) the group's torch.distributed backend is used."""
+    if st.comm is not None:
+        st.comm.all_reduce(t, 0, _stream())
+    elif st.group is not None:             # an explicitly given group is used even when it has one rank
         from .dist import all_reduce_sum
         all_reduce_sum(t, st.group)
 
@@ -320,7 +327,6 @@ _FUSED_REDUCE = os.environ.get("MAU_FUSED_REDUCE", "1") != "0"        # single-l
 _FUSED_BN = os.environ.get("MAU_FUSED_BN", "1") != "0"                # BatchNorm passes fused with pool / head / upsample (A/B switch; bit-identical)
 _FUSED_UP = os.environ.get("MAU_FUSED_UP", "1") != "0"                # (the upsample member of the above, separately switchable)
 _SIDE_STREAMS = {}
-_GRAD_SYNC_ACTIVE = [0]              # number of live dist.GradSync objects with a process group
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":
@@ -649,9 +655,9 @@ class ConvBNReLU(torch.autograd.Function):
         # --- weight gradient: independent of the data gradient given dy ---
         dw = None
         need_dx = needs[0] or (x1 is not None and needs[1]) or (E and needs[2])
-        # (under dist.GradSync the buckets' all-reduces are launched DURING backward and would each wait for the side stream: measured
-        #  15.1 vs 14.2 ms on the one-rank rehearsal -- one stream there)
-        overlap = 0 if _GRAD_SYNC_ACTIVE[0] else _OVERLAP_WGRAD
+        # (under dist.GradSync the buckets' all-reduces run on a communication stream that waits for the side stream by itself:
+        #  the compute stream is not held up, so the overlap stays on -- round 3 had to switch it off there)
+        overlap = _OVERLAP_WGRAD
         side = _side_stream(dev) if (needs[3] and overlap and (need_dx or overlap >= 2)) else None
         deferred = False
         if needs[3]:

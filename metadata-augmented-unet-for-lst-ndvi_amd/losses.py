@@ -9,12 +9,11 @@ In the reference the SSIM values pass through ``torch.Tensor(ssim_vals)`` (:89-9
 term changes the reported number, never the gradient.  ``piq`` (the SSIM provider) is not available in the
 build environment, so the SSIM VALUE follows piq's published default algorithm (11x11 Gaussian, sigma 1.5,
 k1 0.01, k2 0.03, average-pool downsampling by max(1, round(min(H, W)/256))): one fused HIP reduction
-(``mau_ssim_loss``, csrc/ssim.hip), checked on the GPU against the torch-op spelling ``ssim_value_torch`` below.
+(``mau_ssim_loss``, csrc/ssim.hip), checked on the GPU against the torch-op spelling ``ssim_value_torch`` in ``tests/helpers.py`` (test infrastructure, not product).
 That scalar is **parity-unpinned** (no reference fixture can be generated without piq); everything that carries
 gradient is pinned by fixture ``g9_losses.npz``.
 """
 import torch
-import torch.nn.functional as F
 
 from .functional import L1GradientLoss, MSELoss, _require_cuda, _stream
 from ._lib import call, lib
@@ -52,29 +51,6 @@ def ssim_loss(outputs, targets):
     loss = torch.empty(1, dtype=torch.float32, device=o.device)
     call("mau_ssim_loss", o.data_ptr(), t.data_ptr(), ws.data_ptr(), per_image.data_ptr(), loss.data_ptr(), 1, B, C, H, W, _stream())
     return loss.reshape(()), per_image
-
-
-def ssim_value_torch(x, y, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
-    """The same quantity spelled with torch ops (the checker of the HIP kernel in tests/): per-image SSIM averaged over
-    channels (piq.ssim defaults, reduction='none')."""
-    with torch.no_grad():
-        x, y = x / data_range, y / data_range
-        f = max(1, round(min(x.shape[-2:]) / 256))
-        if f > 1:
-            x, y = F.avg_pool2d(x, f), F.avg_pool2d(y, f)
-        c = torch.arange(kernel_size, dtype=x.dtype, device=x.device) - (kernel_size - 1) / 2.0
-        g1 = torch.exp(-(c ** 2) / (2 * sigma ** 2))
-        k = (g1[:, None] * g1[None, :])
-        k = (k / k.sum())[None, None].repeat(x.shape[1], 1, 1, 1)
-        C = x.shape[1]
-        mu_x, mu_y = F.conv2d(x, k, groups=C), F.conv2d(y, k, groups=C)
-        sxx = F.conv2d(x * x, k, groups=C) - mu_x ** 2
-        syy = F.conv2d(y * y, k, groups=C) - mu_y ** 2
-        sxy = F.conv2d(x * y, k, groups=C) - mu_x * mu_y
-        c1, c2 = k1 ** 2, k2 ** 2
-        cs = (2 * sxy + c2) / (sxx + syy + c2)
-        ss = (2 * mu_x * mu_y + c1) / (mu_x ** 2 + mu_y ** 2 + c1) * cs
-        return ss.mean(dim=(-1, -2)).mean(dim=1)
 
 
 def compute_loss_l1_grad_ssim(outputs, targets, lambda_grad=0.1, lambda_ssim=0.5):

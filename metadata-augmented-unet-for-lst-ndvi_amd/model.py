@@ -23,6 +23,7 @@ Extras that the reference does not have (all optional, defaults keep reference b
 """
 from __future__ import annotations
 
+import logging
 import os
 from typing import List, Optional
 
@@ -49,6 +50,7 @@ class _Runtime:
         self.precision = _default_precision()
         self.group = None
         self.world = 1
+        self.comm = None                  # dist.RcclComm for the SyncBN messages (None: local BN, or a group that is not on RCCL)
 
     @property
     def dtype(self) -> torch.dtype:
@@ -82,7 +84,7 @@ class VGGBlock(nn.Module):
         if weight is None and self._group is not None and getattr(conv.weight, "_mau_group", None) is not self._group:
             self._group.add(conv.weight)          # (a deep copy of the network carries new Parameter objects)
         st = BNState(training=self.training and bn.training, C0=x.C, momentum=bn.momentum, eps=bn.eps,
-                     group=rt.group, world=rt.world, grad_enabled=torch.is_grad_enabled(),
+                     group=rt.group, comm=rt.comm, world=rt.world, grad_enabled=torch.is_grad_enabled(),
                      frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1],
                      C1=0 if x1 is None else x1.C, pool=pool, out_view=out_view,
                      head=None if head is None else bool(head_act), up_to=up_to)
@@ -240,14 +242,18 @@ class _NetBase(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def set_sync_bn(self, group=None, world_size: Optional[int] = None):
-        """All-reduce BatchNorm batch statistics over ``group`` (RCCL); ``None``/world 1 = local BN."""
+        """All-reduce BatchNorm batch statistics over ``group`` (RCCL); ``None``/world 1 = local BN.
+        Collective: every rank of the group must call it (it creates the group's SyncBN communicator, ``dist.rccl_comm``)."""
         import torch.distributed as dist
         if group is None and not (dist.is_available() and dist.is_initialized()):
-            self._rt.group, self._rt.world = None, 1
+            self._rt.group, self._rt.world, self._rt.comm = None, 1, None
             return self
+        from .dist import rccl_comm
         g = group if group is not None else dist.group.WORLD
         self._rt.group = g
         self._rt.world = world_size if world_size is not None else dist.get_world_size(g)
+        on_gpu = next(self.parameters()).is_cuda
+        self._rt.comm = rccl_comm(g, "bn") if on_gpu else None
         return self
 
     def _entry(self, maps) -> Act:
@@ -282,6 +288,12 @@ class UrbanPredictor_unet(_NetBase):
     def __init__(self, spatial_channels, seq_len, temporal_dim, meta_features, meta_dim, lstm_dim, out_channels,
                  nb_filter=None, temporal_embeddings=True, metadata_embeddings=True):
         super().__init__()
+        # the reference announces the construction on stdout and through loguru (src/model.py:202-203); same line, through
+        # print and the standard `logging` module (loguru is not a dependency of this package).  MAU_QUIET=1 silences the print.
+        msg = f'UrbanPredictor_unet initialized with temporal_embeddings={temporal_embeddings}, metadata_embeddings={metadata_embeddings}'
+        logging.getLogger("mau_amd").info(msg)
+        if os.environ.get("MAU_QUIET", "0") != "1":
+            print(msg)
         if nb_filter is None:
             nb_filter = [32, 64, 128, 256, 512]
         self.temporal_dim = temporal_dim

@@ -44,6 +44,29 @@ def _make_capturable(optimizer: torch.optim.Optimizer):
                     st["step"] = st["step"].to(p.device, dtype=torch.float32)
 
 
+def _grad_accumulator(p: torch.Tensor):
+    with torch.enable_grad():
+        return p.view_as(p).grad_fn.next_functions[0][0]
+
+
+def live_autograd_graph_params(params) -> list:
+    """Indices of the parameters whose AccumulateGrad node is being KEPT ALIVE by something -- an autograd graph of an earlier
+    step that still exists (a kept ``loss`` / ``outputs`` with grad_fn, a reference cycle).  A parameter owns its accumulator only
+    weakly: with no graph alive the node dies as soon as the probe lets go of it and the second look finds a fresh one; a node
+    that survives (its ``metadata`` dict, which lives with the C++ node, still carries the mark) is held by a graph."""
+    params = [p for p in params if p.requires_grad and p.is_leaf]
+    mark = object()
+    for p in params:
+        _grad_accumulator(p).metadata["mau_capture_probe"] = mark
+    held = []
+    for i, p in enumerate(params):
+        node = _grad_accumulator(p)
+        if node.metadata.get("mau_capture_probe") is mark:
+            del node.metadata["mau_capture_probe"]
+            held.append(i)
+    return held
+
+
 class GraphedTrainStep:
     """``criterion(outputs, targets)`` returns the reference's loss dict (``{'total': ...}``, src/utils/losses.py) or a
     scalar tensor.  ``clip_grad_norm``: max norm of ``torch.nn.utils.clip_grad_norm_`` (src/train.py:253-254), 0 = off.
@@ -94,6 +117,14 @@ class GraphedTrainStep:
         # AccumulateGrad nodes, bound to the stream they were created on; the captured backward would re-use them and make the engine
         # synchronise with that stream -- on ROCm 7.2 the capture then dies in hipStreamEndCapture instead of raising.
         gc.collect()
+        held = live_autograd_graph_params(self.model.parameters())
+        if held:
+            raise RuntimeError(
+                f"GraphedTrainStep: an autograd graph of an earlier step is still alive (it holds the AccumulateGrad nodes of {len(held)} "
+                "parameters, created on another stream) -- typically a kept `loss` / `outputs` tensor that still has a grad_fn, or a "
+                "reference cycle through an autograd ctx.  Capturing now would make the engine synchronise the capture with that "
+                "stream and end in hipStreamEndCapture taking the process down.  Drop or .detach() those tensors before the "
+                "capturing call (the step itself returns detached tensors).")
         # Who re-packs the convolution weights?  torch's optimizers: the captured forward starts with the (captured) multi-tensor
         # re-pack.  optim.AdamW writes the packs together with the update: the captured step then contains NO separate pack -- the
         # forward of replay k reads what the optimizer of replay k - 1 (or of the last warm-up step) wrote.
@@ -143,9 +174,10 @@ class GraphedTrainStep:
                 dst.copy_(src, non_blocking=True)
         elif any(a.data_ptr() != b.data_ptr() or a.shape != b.shape for a, b in zip(self._in, batch)):
             raise ValueError("GraphedTrainStep(copy_inputs=False): pass the tensors of the captured call (fill them in place)")
-        if self._self_packing and F_._GENERATION[0] != self._expect_gen:
-            # something outside changed parameters since the last replay (another optimizer's step, mark_params_updated(), an eager
-            # step): the graph holds no pack launch of its own, so the packs are brought up to date before it runs
+        if self._self_packing:
+            # the graph holds no pack launch of its own.  If something outside changed parameters since the last replay -- another
+            # optimizer's step or mark_params_updated() (generation), load_state_dict / an in-place write (tensor versions) -- the
+            # packs are brought up to date before it runs; otherwise ensure() finds them fresh and launches nothing
             for pg in self._groups:
                 for code in list(pg._state):
                     pg.ensure(code)

@@ -95,7 +95,10 @@ json.dump(summary, open(os.path.join(dst, "dominant_kernel_summary.json"), "w"),
 dom = summary["conv3x3_bf16_kernel (dominant: forward + data gradient)"]
 pj = os.path.join(root, "pmc_summary.json")
 allk = json.load(open(pj)) if os.path.exists(pj) else {}
-allk[key] = {"hbm_bytes_per_launch": dom.get("hbm_bytes_per_launch_pmc"), "mfma_busy": dom.get("mfma_busy_fraction"),
+import hashlib
+libp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "metadata-augmented-unet-for-lst-ndvi_amd", "libmau_hip.so")
+lib_sha = hashlib.sha256(open(libp, "rb").read()).hexdigest()       # bench.py quotes these counters only for the SAME binary
+allk[key] = {"lib_sha256": lib_sha, "hbm_bytes_per_launch": dom.get("hbm_bytes_per_launch_pmc"), "mfma_busy": dom.get("mfma_busy_fraction"),
              "avg_launch_us_rocprof": dom["avg_launch_us_rocprof"], "launches": dom["launches"], "l2_hit_rate": dom.get("l2_hit_rate"),
              "lds_bank_conflict_fraction": dom.get("lds_bank_conflict_fraction"), "command": cmd,
              "mfma_busy_long": dom.get("mfma_busy_long"), "clock_ghz_long": dom.get("clock_ghz_long"), "frac_long": dom.get("frac_executed_long"),

@@ -254,3 +254,19 @@ def test_asan_host_build_of_the_c_abi():
     csrc = os.path.join(ROOT, "metadata-augmented-unet-for-lst-ndvi_amd", "csrc")
     p = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "asan host check OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_live_autograd_graph_probe_cpu():
+    """train_graph.live_autograd_graph_params (the guard in front of every capture): a parameter's AccumulateGrad node survives
+    only while some autograd graph holds it."""
+    import mau_amd  # noqa: F401
+    from mau_amd.train_graph import live_autograd_graph_params
+    lin = torch.nn.Linear(4, 4)
+    assert live_autograd_graph_params(lin.parameters()) == []
+    kept = lin(torch.randn(2, 4)).sum()
+    assert live_autograd_graph_params(lin.parameters()) == [0, 1]
+    del kept
+    assert live_autograd_graph_params(lin.parameters()) == []
+    hooks = [p.register_post_accumulate_grad_hook(lambda p: None) for p in lin.parameters()]      # (dist.GradSync's hooks pin nothing)
+    lin(torch.randn(2, 4)).sum().backward()
+    assert live_autograd_graph_params(lin.parameters()) == []

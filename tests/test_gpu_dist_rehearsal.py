@@ -76,15 +76,32 @@ import os, sys, torch
 sys.path.insert(0, os.environ["MAU_ROOT"])
 import torch.distributed as dist
 import mau_amd
-from mau_amd.dist import GradSync, all_reduce_sum
+from mau_amd.dist import GradSync, all_reduce_sum, rccl_comm, RcclComm, NCCL_AVG, NCCL_SUM
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29519", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 assert dist.get_backend() == "nccl"
+DIRECT = os.environ.get("MAU_RCCL_DIRECT", "1") != "0"
 # the collectives the data-parallel path issues, on device memory, through RCCL itself
 t64 = torch.arange(128, dtype=torch.float64, device="cuda"); all_reduce_sum(t64, dist.group.WORLD)
 t32 = torch.ones(1 << 20, device="cuda"); h = all_reduce_sum(t32[17:], dist.group.WORLD, async_op=True); h.wait()
 torch.cuda.synchronize()
 assert torch.equal(t64.cpu(), torch.arange(128, dtype=torch.float64)) and float(t32.sum()) == float(1 << 20)
+if DIRECT:
+    # ... and the way the product issues them: ncclAllReduce called directly on a named stream (dist.RcclComm), fp64 SUM on the
+    # current stream (SyncBN message), fp32 AVG of an arena segment on a side stream ordered by events (gradient bucket)
+    c = rccl_comm(dist.group.WORLD, "bn"); assert isinstance(c, RcclComm) and c.world == 1 and rccl_comm(dist.group.WORLD, "bn") is c
+    c2 = rccl_comm(dist.group.WORLD, "grad"); assert c2 is not c
+    t64 = torch.arange(257, dtype=torch.float64, device="cuda") * 0.5; c.all_reduce(t64, NCCL_SUM)
+    side = torch.cuda.Stream(); arena = torch.zeros(1 << 22, device="cuda"); arena[1000:].fill_(3.0)
+    side.wait_stream(torch.cuda.current_stream()); c2.all_reduce(arena[1000:], NCCL_AVG, side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    assert torch.equal(t64.cpu(), torch.arange(257, dtype=torch.float64) * 0.5) and float(arena.sum()) == 3.0 * ((1 << 22) - 1000)
+    try:
+        c.all_reduce(torch.zeros(4)); raise SystemExit("a host tensor must be refused")
+    except RuntimeError:
+        pass
+else:
+    assert rccl_comm(dist.group.WORLD, "bn") is None
 kw = dict(model_type="unet", spatial_channels=6, seq_len=10, temporal_dim=8, meta_features=4, meta_dim=8, lstm_dim=12,
           out_channels=2, base_filters=8, temporal_embeddings=False, metadata_embeddings=True)
 g = torch.Generator().manual_seed(3)
@@ -99,7 +116,7 @@ for prec in ("fp32", "bf16"):
         if synced:
             net.set_sync_bn(dist.group.WORLD)
             sync = GradSync(net, dist.group.WORLD, bucket_bytes=64 << 10)
-            assert len(sync.buckets) > 1
+            assert len(sync.buckets) > 1 and (sync.comm is not None) == DIRECT and (net.model._rt.comm is not None) == DIRECT
         for step in range(2):                       # gradients accumulate over the two passes (no optimizer: Adam
             loss = mau_amd.compute_loss_mse(net(x, ts, md), tgt)["total"]     # would amplify rounding noise of ~0 grads)
             if sync: sync.begin()
@@ -108,6 +125,10 @@ for prec in ("fp32", "bf16"):
         torch.cuda.synchronize()
         res[(prec, synced)] = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if "running" in k}
         res[(prec, synced)].update({"grad." + k: p.grad.float().cpu() for k, p in net.named_parameters() if p.grad is not None})
+if os.environ.get("MAU_TEST_SHORT") == "1":
+    torch.save(res, os.path.join(os.environ["MAU_OUT"], "rccl1.pt"))
+    dist.barrier(); dist.destroy_process_group()
+    sys.exit(0)
 # U-Net++ with the temporal branch: the LSTM runs on its side stream under the process group (GradSync waits for every stream that
 # produced a gradient of a bucket); 3 steps with fused AdamW, synced vs plain, must agree
 kw2 = dict(model_type="unet++", spatial_channels=6, seq_len=24, temporal_dim=16, meta_features=4, meta_dim=16, lstm_dim=24, out_channels=2, base_filters=16)
@@ -199,6 +220,19 @@ def test_rccl_collectives_one_rank_group(tmp_path):
     assert float(res["train_best"]) < float("inf")
 
 
+def test_process_group_nccl_path_still_works(tmp_path):
+    """MAU_RCCL_DIRECT=0: the same messages through ProcessGroupNCCL (round 3's path, kept as the A/B switch)."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.replace("29519", "29521"))
+    env = dict(os.environ, MAU_ROOT=ROOT, MAU_OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", MAU_RCCL_DIRECT="0", MAU_TEST_SHORT="1")
+    subprocess.run([sys.executable, str(script)], check=True, env=env, timeout=300)
+    res = torch.load(tmp_path / "rccl1.pt")
+    a, b = res[("fp32", False)], res[("fp32", True)]
+    for k in a:
+        err = float((a[k] - b[k]).abs().max())
+        assert err < 1e-4 * float(a[k].abs().max()) or err < 1e-6, (k, err)
+
+
 def test_bench_self_launches_two_ranks(tmp_path):
     """``python bench.py --gpus 2`` outside torch.distributed.run must start its own two ranks (child processes; the
     parent never touches the GPU), and print ONE JSON line with n_gpus 2; N = 1 keeps printing its line directly.
@@ -218,3 +252,38 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert p1.returncode == 0, p1.stderr[-3000:]
     rec1 = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])
     assert rec1["n_gpus"] == 1 and rec1["rccl_ranks"] == 1 and "cpu_baseline" not in rec1
+
+
+def test_bench_inference_replicas_two_ranks():
+    """BASELINE configs[4] names N-GPU inference: ``bench.py --infer --gpus 2`` = two independent replicas (no collective on
+    the data path), each with its GraphedInference session; one line, value = images of both ranks / max-over-ranks time."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MAU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--infer", "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "64", "--no-cpu-baseline", "--precision", "fp16", "--repeats", "2"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["metric"].startswith("inference images/sec")
+    assert "hipGraph replay" in rec["config"]["launch"] and rec["timed_regions"]["repeats"] == 2 and rec["value"] > 0
+
+
+def test_bench_under_torchrun_each_rank_supervises_its_worker():
+    """The driver's launch line for N > 1 (``python -m torch.distributed.run ... bench.py --gpus N``): every launched process is the
+    supervisor of one worker; the workers meet on a rendezvous of their own and rank 0's line comes out exactly once."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MAU_DP_GRAPH")}
+    env.update(MAU_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "3", "--batch", "2", "--size", "64", "--no-cpu-baseline", "--repeats", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    # two ranks share one GPU here, so the collectives are gloo's (host-staged: not capturable) -- the captured attempt fails in
+    # every worker and the supervisors fall back to fresh eager workers: the measurement survives
+    assert rec["n_gpus"] == 2 and rec["config"]["sync_bn"] is True and rec["value"] > 0
+    assert rec["config"]["launch"].startswith("eager") and "falling back" in p.stderr

@@ -1,0 +1,152 @@
+"""Parity at the sizes the bench runs (BASELINE configs[1] and configs[2]): ONE 16-bit training step of the full-width network
+through the product's step driver -- ``GraphedTrainStep`` (hipGraph replay) + ``mau_amd.AdamW`` -- against the CPU oracle on the
+same seed: output, loss, every parameter's gradient, the post-step weights, the BatchNorm buffers.
+
+Why a test of its own: the kernels these shapes select (the big-tile ``<128,4,8>`` / ``<64,4,8>`` 16x16x32 stage-pair loop,
+``wgrad16_kernel``, the gradient arena, ``adamw_pack_kernel``) are never selected by the small fixtures.  The test ASSERTS that
+selection (pixel-tile counts of the level-0 and level-1 layers), so a smaller batch cannot silently test other code.
+
+Yardstick (as in test_gpu_model.py): the error of the REFERENCE's own operators under torch's CPU bf16 autocast against their
+fp32 result on the same inputs -- the inherent bf16 noise of this network.  The HIP path (bf16 operands, fp32 accumulation, fp32
+BatchNorm statistics, fp32 master weights) must stay within 1.5x that (+ a floor), per parameter and globally.
+CPU cost on the GPU box: fp32 oracle step + autocast pass, ~1-2 min per test (``MAU_TEST_FULL_B`` lowers the U-Net batch).
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import unet_ref as R
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+LR, WD = 1e-4, 1e-3                     # conf/config.yaml:41,48,52 (bench.py's optimizer)
+
+
+def _oracle_step(model_type, sd0, batch, flags, autocast):
+    """(out, loss, grads, sd after one AdamW step) of the oracle in fp32, or with the forward under CPU bf16 autocast."""
+    x, ts, md, tgt = batch
+    sd = R.clone_state(sd0, requires_grad=True)
+    params = [sd[k] for k in sd if R.is_param(k)]
+    opt = torch.optim.AdamW(params, lr=LR, weight_decay=WD)
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = R.forward(model_type, sd, x, ts, md, True, **flags)
+        out = out.float()
+    else:
+        out = R.forward(model_type, sd, x, ts, md, True, **flags)
+    loss = R.loss_mse(out, tgt)["total"]
+    loss.backward()
+    grads = {k: v.grad.detach().clone() for k, v in sd.items() if R.is_param(k) and v.grad is not None}
+    opt.step()
+    return out.detach(), float(loss), grads, {k: v.detach().clone() for k, v in sd.items()}
+
+
+def _hip_step(mau, net, sd0, batch, warm_batch):
+    """One step from ``sd0`` with a fresh optimizer THROUGH THE GRAPH: the step driver captures on its third call, so two eager
+    warm-up steps and the capturing step run first (on another batch); then weights, BatchNorm buffers and optimizer state are
+    put back IN PLACE (the graph holds their addresses) and one replay is the step under test."""
+    opt = mau.AdamW(net.parameters(), lr=LR, weight_decay=WD)
+    step = mau.GraphedTrainStep(net, opt, mau.compute_loss_mse, warmup=2, copy_inputs=True)
+    for _ in range(3):
+        step(*warm_batch)
+    assert step.graph is not None
+    net.load_state_dict(sd0)                                    # in-place copies; bumps the versions -> the packs are rebuilt before the replay
+    for st in opt.state.values():
+        st["step"].zero_()
+        st["exp_avg"].zero_()
+        st["exp_avg_sq"].zero_()
+    loss = step(*batch)
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().float().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    return step.outputs.float().cpu(), float(loss), grads, {k: v.detach().cpu() for k, v in net.state_dict().items()}
+
+
+def _compare(tag, hip, ref, yard, sd0, nograd_ok=()):
+    out, loss, grads, sd1 = hip
+    rout, rloss, rgrads, rsd1 = ref
+    yout, yloss, ygrads, ysd1 = yard
+    e_out, y_out = rel_l2(out, rout), rel_l2(yout, rout)
+    print(f"{tag}: output relL2 {e_out:.4f} (autocast yardstick {y_out:.4f}); loss {loss:.6f} vs {rloss:.6f} (autocast {yloss:.6f})")
+    assert e_out <= 1.5 * y_out + 1e-2
+    assert abs(loss - rloss) <= 1.5 * abs(yloss - rloss) + 5e-3 * abs(rloss)
+    assert set(grads) == set(rgrads) - set(nograd_ok), set(grads) ^ set(rgrads)
+    num = den = ynum = 0.0
+    worst = (0.0, "", 0.0)
+    for k, g in rgrads.items():
+        if k.endswith((".conv1.bias", ".conv2.bias")):
+            # a conv bias in front of train-mode BatchNorm has an identically zero gradient: exact zeros here, rounding noise there
+            assert float(grads[k].abs().max()) == 0.0 and float(g.abs().max()) < 1e-2 * max(float(v.abs().max()) for v in rgrads.values()), k
+            continue
+        e, y = rel_l2(grads[k], g), rel_l2(ygrads[k], g)
+        num += float(((grads[k].double() - g.double()) ** 2).sum())
+        ynum += float(((ygrads[k].double() - g.double()) ** 2).sum())
+        den += float((g.double() ** 2).sum())
+        if e - 1.5 * y > worst[0] - 1.5 * worst[2] or not worst[1]:
+            worst = (e, k, y)
+        assert e <= 1.5 * y + 3e-2, (k, e, y)                   # every parameter, against the reference's own bf16 noise on it
+    e_g, y_g = (num / den) ** 0.5, (ynum / den) ** 0.5
+    print(f"{tag}: gradients relL2 over all parameters {e_g:.4f} (yardstick {y_g:.4f}); tightest margin on {worst[1]}: {worst[0]:.4f} vs {worst[2]:.4f}")
+    assert e_g <= 1.5 * y_g + 1e-2
+    # the AdamW step: first-step updates are ~ -lr * sign(g) (+ weight decay): compared as update vectors; the bound is again the
+    # reference's own -- sign flips of near-zero gradient elements under bf16 are what both see
+    unum = uden = uynum = 0.0
+    for k, v in rsd1.items():
+        a = sd1[k]
+        if not v.is_floating_point():
+            assert torch.equal(a, v), k                          # num_batches_tracked
+            continue
+        if "running_" in k:
+            assert rel_l2(a, v) <= 1.5 * rel_l2(ysd1[k], v) + 5e-3, k
+            continue
+        if k.endswith((".conv1.bias", ".conv2.bias")) or k in nograd_ok:
+            continue
+        du, dr, dy = (a - sd0[k]).double(), (v - sd0[k]).double(), (ysd1[k] - sd0[k]).double()
+        assert float((a - v).abs().max()) <= 2.05 * LR, k          # no element can move further than a flipped sign
+        unum += float(((du - dr) ** 2).sum())
+        uynum += float(((dy - dr) ** 2).sum())
+        uden += float((dr ** 2).sum())
+    e_u, y_u = (unum / uden) ** 0.5, (uynum / uden) ** 0.5
+    print(f"{tag}: AdamW update relL2 {e_u:.4f} (yardstick {y_u:.4f})")
+    assert e_u <= 1.5 * y_u + 2e-2
+
+
+def test_config2_unet_b32_bf16_graph_step_vs_oracle():
+    """BASELINE configs[1]: U-Net base 64, B=32 x 6 x 256 x 256 + 4-dim metadata, bf16 -- the workload of ``python bench.py``."""
+    import mau_amd as mau
+    from mau_amd import functional as F_
+    B = int(os.environ.get("MAU_TEST_FULL_B", "32"))
+    flags = dict(temporal_embeddings=False, metadata_embeddings=True)
+    torch.manual_seed(0)
+    net = mau.UrbanPredictor("unet", 6, 10, 64, 4, 64, 96, 2, base_filters=64, **flags)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    batch = R.synthetic_batch(B)
+    warm = R.synthetic_batch(B, seed=77)
+    # the variants under test: level 0 runs the 64-wide big tile (64x16 pixels per item), level 1 the 128-wide one
+    code = F_.MAU_BF16
+    t0 = F_.lib.mau_conv3x3_num_pixel_tiles(code, B, 256, 256, 64)
+    t1 = F_.lib.mau_conv3x3_num_pixel_tiles(code, B, 128, 128, 128)
+    # (slab rows = wave rows x pixel tiles: <64,4,8> = 8 wave rows on 64x16-pixel tiles, <128,4,8> = 4 on 32x16 -- conv3x3_bf16.hip pick_variant)
+    assert t0 == 8 * B * (256 // 64) * (256 // 16) and t1 == 4 * B * (128 // 32) * (128 // 16), (t0, t1)
+    ref = _oracle_step("unet", sd0, batch, flags, autocast=False)
+    yard = _oracle_step("unet", sd0, batch, flags, autocast=True)
+    net = net.cuda().set_precision("bf16").train()
+    hip = _hip_step(mau, net, sd0, tuple(v.cuda() for v in batch), tuple(v.cuda() for v in warm))
+    nograd = [k for k in sd0 if k.startswith("model.temporal_encoder.")]
+    _compare(f"config 2 (B={B})", hip, ref, yard, sd0, nograd_ok=nograd)
+
+
+def test_config3_unetpp_b16_bf16_graph_step_vs_oracle():
+    """BASELINE configs[2]: U-Net++ (decoder-wide embedding concat, row buffers, folded embedding), B=16, 256x256, bf16."""
+    import mau_amd as mau
+    B = int(os.environ.get("MAU_TEST_FULL_B_UPP", "16"))
+    torch.manual_seed(0)
+    net = mau.UrbanPredictor("unet++", 6, 10, 64, 4, 64, 96, 2, base_filters=64)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    batch = R.synthetic_batch(B)
+    warm = R.synthetic_batch(B, seed=77)
+    ref = _oracle_step("unet++", sd0, batch, {}, autocast=False)
+    yard = _oracle_step("unet++", sd0, batch, {}, autocast=True)
+    net = net.cuda().set_precision("bf16").train()
+    hip = _hip_step(mau, net, sd0, tuple(v.cuda() for v in batch), tuple(v.cuda() for v in warm))
+    _compare(f"config 3 (B={B})", hip, ref, yard, sd0)

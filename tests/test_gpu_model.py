@@ -64,10 +64,22 @@ def test_fp32_parity_full_model(mau, name):
             assert torch.equal(a, v), k
         elif "running_" in k:
             assert rel_err(a, v) < 1e-3, k
-        else:
-            # one AdamW step moves each weight by ~lr*sign-like update; conv biases in front of BN see pure
-            # rounding-noise gradients in the reference (|update| <= lr), exact zeros here
+        elif k.endswith((".conv1.bias", ".conv2.bias")):
+            # conv biases in front of BN see pure rounding-noise gradients in the reference (its first AdamW step moves them by
+            # up to lr in a random direction), exact zeros here (only the weight decay moves them): |difference| <= lr (+ margin)
             assert float((a - v).abs().max()) <= 2.5 * m["lr"], k
+        else:
+            # every other parameter: the first AdamW step is ~ -lr * sign(g), so an update in the WRONG direction is 2 lr away.
+            # Bound: 99.9 % of a tensor's elements within 0.2 lr of the reference's, none further than one flipped sign (an element
+            # whose gradient is rounding noise around zero may flip: g / (|g| + eps) is discontinuous there), and the update
+            # vector as a whole within 5 % (relative L2) of the reference's
+            diff = (a - v).abs()
+            close = float((diff <= 0.2 * m["lr"]).float().mean())
+            assert close >= 0.999 or diff.numel() - int((diff <= 0.2 * m["lr"]).sum()) <= 1, (k, close)
+            assert float(diff.max()) <= 2.05 * m["lr"], k
+            upd_ref = v - sub(d, "sd0")[k]
+            if float(upd_ref.norm()) > 0:
+                assert rel_l2(a - sub(d, "sd0")[k], upd_ref) <= 5e-2, (k, rel_l2(a - sub(d, "sd0")[k], upd_ref))
 
 
 def _autocast_yardstick(d, m):
@@ -754,6 +766,29 @@ def test_graphed_train_step_unetpp_row_buffers(mau, monkeypatch):
     for k in a[1]:
         assert torch.equal(a[1][k], b[1][k]), k
     assert torch.equal(a[2], b[2])
+
+
+def test_capture_refuses_a_live_autograd_graph(mau):
+    """A loss / output of an earlier step that still carries its grad_fn keeps that step's AccumulateGrad nodes alive, bound to the
+    stream they were created on; a capture that meets them ends in hipStreamEndCapture taking the process down (round 3's records).
+    The step driver now finds them BEFORE capturing and raises a Python error that names the cause; once the tensor is dropped
+    the same object captures and replays."""
+    torch.manual_seed(5)
+    net = mau.UrbanPredictor("unet", 6, 10, 8, 4, 8, 12, 2, base_filters=8, temporal_embeddings=False, metadata_embeddings=True).cuda().train()
+    opt = mau.AdamW(net.parameters(), lr=1e-3)
+    step = mau.GraphedTrainStep(net, opt, mau.compute_loss_mse, warmup=1)
+    g = torch.Generator().manual_seed(6)
+    x, ts, md, tgt = torch.randn(2, 6, 32, 32, generator=g).cuda(), torch.randn(2, 10, generator=g).cuda(), torch.randn(2, 4, generator=g).cuda(), torch.randn(2, 2, 32, 32, generator=g).cuda()
+    step(x, ts, md, tgt)                                         # warm-up (eager)
+    kept = mau.compute_loss_mse(net(x, ts, md), tgt)["total"]    # user code holding on to a graph
+    with pytest.raises(RuntimeError, match="autograd graph of an earlier step is still alive"):
+        step(x, ts, md, tgt)
+    assert step.graph is None
+    del kept
+    step.calls -= 1                                              # (the refused call did not happen)
+    l1 = float(step(x, ts, md, tgt))
+    l2 = float(step(x, ts, md, tgt))
+    assert step.graph is not None and l2 < l1
 
 
 def test_inplace_op_on_a_row_buffer_raises_in_backward(mau, monkeypatch):
