@@ -45,7 +45,7 @@ extern "C" {
 typedef void* mau_stream_t;
 
 /* ---- library ---------------------------------------------------------- */
-#define MAU_ABI_VERSION 2  /* 2: single-launch reductions (tickets), multi-tensor weight pack, fused BatchNorm passes */
+#define MAU_ABI_VERSION 3  /* 2: single-launch reductions (tickets), multi-tensor weight pack, fused BatchNorm passes; 3: first-layer kernels */
 int mau_abi_version(void);
 const char* mau_last_error(void);
 /* 0 when the current HIP device is a gfx950 (MI355X); MAU_ERR_DEVICE otherwise. */
@@ -94,6 +94,22 @@ int mau_conv3x3_pack_weights_multi(const void* descs, int n, int total_tiles, in
  * channels: one per 8x16-pixel tile for MAU_F32; one per (workgroup tile of 16x16 or 32x16 pixels, wave row) for
  * MAU_BF16 -- the tile height is chosen per layer from how well its work items fill the 256 CUs. */
 int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout);
+/* The network's FIRST convolution (reference src/model.py:222 / :67 conv0_0.conv1; nn.Conv2d(spatial_channels, 64, 3, padding=1),
+ * src/model.py:12) for inputs of at most mau_conv3x3_first_max_channels() = 8 channels, 16-bit modes: reads the input AS THE
+ * REFERENCE'S collate_fn DELIVERS IT -- x (N,Cin,H,W) fp32 contiguous (src/dataset.py:99-106) -- and the fp32 master weights
+ * w (Cout,Cin,3,3) directly (no layout kernel, no weight pack); writes y (N,H,W,ldy) in `dtype` (MAU_BF16 | MAU_F16; ldy % 8 == 0,
+ * channels [Cout, ldy) zero) = conv + bias, and either
+ *   slab != NULL : BatchNorm partial sums from the fp32 accumulators, [rows][2 * roundup(Cout,64)] with
+ *                  rows = mau_conv3x3_first_rows(N,H,W) (one row per persistent workgroup; feed it to
+ *                  mau_bn_stats_finalize_train / mau_bn_stats_sums_f64 exactly like the slab of mau_conv3x3_fwd), or
+ *   post_scale/post_shift != NULL : y = relu(post_scale * (conv + bias) + post_shift) (eval-mode BatchNorm + ReLU folded in).
+ * x8 (optional): the input converted to `dtype` as an NHWC tensor of 8 channels (N,H,W,8), channels >= Cin zero -- what the
+ * weight gradient of this layer reads (mau_conv3x3_wgrad2 with ldx = 8); written from the same pass over x. */
+int mau_conv3x3_first_max_channels(void);
+int mau_conv3x3_first_rows(int N, int H, int W);
+int mau_conv3x3_first_fwd(const float* x_nchw, int Cin, const float* w_oihw, const float* bias, const float* post_scale,
+                          const float* post_shift, void* y, int ldy, int Cout, float* slab, void* x8, int dtype, int N, int H,
+                          int W, mau_stream_t stream);
 /* y = conv3x3(cat([x, broadcast(emb)], C)) + bias.
  *   x     NHWC-ld with C0 channels;
  *   emb   optional fp32 (N,E): E extra input channels, constant over (y,x) inside the image and

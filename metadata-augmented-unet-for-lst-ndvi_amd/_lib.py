@@ -39,6 +39,9 @@ PROTOTYPES = {
     "mau_conv3x3_pack_desc_fill": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_pack_weights_multi": (_i, [_p, _i, _i, _i, _p]),
     "mau_conv3x3_num_pixel_tiles": (_i, [_i, _i, _i, _i, _i]),
+    "mau_conv3x3_first_max_channels": (_i, []),
+    "mau_conv3x3_first_rows": (_i, [_i, _i, _i]),
+    "mau_conv3x3_first_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_fwd": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_fwd2": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),

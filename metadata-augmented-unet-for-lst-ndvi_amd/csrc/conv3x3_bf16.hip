@@ -279,7 +279,7 @@ __device__ __forceinline__ void dma_issue_buf(__amdgpu_buffer_rsrc_t rs, int vof
 // stage pair between the MFMAs: -1.5...3 % of a launch), with it the second source's lane offsets (5 registers).
 template <int BN, int MT, int NW, int EPI, bool F16, bool FAST, bool M16, bool ONE = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
-  static_assert(!M16 || (MT == 4 && NW == 8 && FAST), "the 16x16x32 loop: 128-pixel wave strips, buffer-addressed loader");
+  static_assert(!M16 || (MT == 4 && (NW == 8 || (NW == 4 && BN == 64)) && FAST), "the 16x16x32 loop: 128-pixel wave strips, buffer-addressed loader");
   static_assert(!ONE || M16, "single-source instantiations exist for the 16x16x32 variants only");
   using G = Geo<BN, MT, NW>;
   constexpr int WN = G::WN, WM = G::WM, TH = G::TH, HPIX = G::HPIX, HALO_Q = G::HALO_Q, HALO_BYTES = G::HALO_BYTES;
@@ -495,7 +495,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
     if constexpr (M16) {
       using PS = PairSched;
       static_assert(kPairSched.ok(), "pair schedule");
-      static_assert(PER_WAVE <= 7, "DMA slots of the pair schedule");
+      // a wave-DMA every DSP MFMAs of a half pair: <*,4,8> issue up to 7 per stage, <64,4,4> (half the waves for 0.68 of the bytes) 10
+      constexpr int DSP = PER_WAVE <= 7 ? 14 : 12;
+      static_assert(PER_WAVE <= 10 && 10 + (PER_WAVE - 1) * DSP < 128, "DMA slots of the pair schedule");
       const bool up = lane >= 32;
       const unsigned laneA = ((wm * 8) * HS + (lane & 15)) * ROWB + 16 * ((lane >> 4) & 1);
       const unsigned laneB = HALO_BYTES + (wn * 64 + (lane & 15)) * ROWB + 16 * ((lane >> 4) & 1);
@@ -548,12 +550,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
             static_for<kPairSched.lo[M], kPairSched.lo[M + 1]>([&](auto kc) { issue_read(kc); });
             __builtin_amdgcn_sched_barrier(0);
           }
-          if constexpr (M < 128 && M % 14 == 10 && M / 14 < PER_WAVE && !ABL_NODMA) {
-            MAU_ISSUE_SLOT(M / 14, stage ^ 1, chunk + 1);
+          if constexpr (M < 128 && M % DSP == 10 && M / DSP < PER_WAVE && !ABL_NODMA) {
+            MAU_ISSUE_SLOT(M / DSP, stage ^ 1, chunk + 1);
             __builtin_amdgcn_sched_barrier(0);
           }
-          if constexpr (M >= 160 && (M - 160) % 14 == 10 && (M - 160) / 14 < PER_WAVE && !ABL_NODMA) {
-            MAU_ISSUE_SLOT((M - 160) / 14, stage, fchunkB);
+          if constexpr (M >= 160 && (M - 160) % DSP == 10 && (M - 160) / DSP < PER_WAVE && !ABL_NODMA) {
+            MAU_ISSUE_SLOT((M - 160) / DSP, stage, fchunkB);
             __builtin_amdgcn_sched_barrier(0);
           }
         });
@@ -917,7 +919,7 @@ static int launch(const ConvP& p, hipStream_t st) {
   using G = Geo<BN, MT, NW>;
   MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, false>);
   MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false, false>);
-  if constexpr (MT == 4 && NW == 8) {
+  if constexpr (MT == 4) {
     MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>);
     MAU_LDS_ATTR(G::LDS, (&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true, true>));
   }
@@ -952,7 +954,7 @@ static int launch(const ConvP& p, hipStream_t st) {
   // (MAU_CONV_M16=0: the 32x32x16 loop everywhere, for same-box A/B timing)
   static const bool m16 = getenv("MAU_CONV_M16") == nullptr || atoi(getenv("MAU_CONV_M16")) != 0;
   bool done = false;
-  if constexpr (MT == 4 && NW == 8) {
+  if constexpr (MT == 4) {
     if (m16 && q.fast && q.nChunks % 2 == 0) {
       static const bool no_one = getenv("MAU_CONV_ONE") != nullptr && atoi(getenv("MAU_CONV_ONE")) == 0;      // A/B switch
       if (p.C1 == 0 && p.E == 0 && !no_one)
@@ -978,8 +980,11 @@ static int launch(const ConvP& p, hipStream_t st) {
 //  more than the overlap gained, 207 vs 182 us on the 64->64 level-0 layer; <*,8,4> = one wave per SIMD with 256
 //  accumulators in AGPRs, 0.48 instead of 0.75 fragment reads per MFMA -- 10-90 % slower, nothing hides its epilogue.)
 struct Variant {
-  int th, nw;                      // tile rows, waves per workgroup
+  int th, nw;                      // tile rows, waves per workgroup   ((32, 4) = <64,4,4>; (32, 8) = <64,2,8> | <128,4,8>)
 };
+#ifndef MAU_CONV_L0_DEFAULT
+#define MAU_CONV_L0_DEFAULT 1
+#endif
 static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
   static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 64;
   const bool wide = CoutPad % 128 == 0;
@@ -1000,6 +1005,13 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
       best = {th, nw};
     }
   }
+  // Level 0 (64 output channels, the 64-row tile wins the score): TWO independent 4-wave workgroups per CU, each on a 32 x 16 pixel
+  // tile (<64,4,4>, the same 128-pixel wave strips and 16x16x32 stage-pair loop).  At K = 64..192 an item is 2-6 stage pairs and ends
+  // in an epilogue that moves 128 KB per CU through the store path with the matrix pipes idle (all eight waves of the one resident
+  // workgroup are in it together); two workgroups drift apart, one's epilogue runs beside the other's multiply loop.  Costs: the weight
+  // slab is fetched by both (L2 hits; 74 instead of 55 DMA bytes per pixel).  MAU_CONV_L0: 1 = on, 0 = off (A/B).
+  static const int l0 = getenv("MAU_CONV_L0") ? atoi(getenv("MAU_CONV_L0")) : MAU_CONV_L0_DEFAULT;
+  if (l0 && !wide && best.th == 64 && th_max >= 64) best = {32, 4};
   return best;
 }
 }  // namespace v2
@@ -1011,27 +1023,29 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
 #define MAU_CONV_TU_NAME2(e, f) launch_conv_bf16_tu_e##e##_f##f
 #define MAU_CONV_TU_NAME(e, f) MAU_CONV_TU_NAME2(e, f)
 #ifdef MAU_CONV_TU_EPI
-int MAU_CONV_TU_NAME(MAU_CONV_TU_EPI, MAU_CONV_TU_F16)(const ConvP& p, int th, hipStream_t st) {
+int MAU_CONV_TU_NAME(MAU_CONV_TU_EPI, MAU_CONV_TU_F16)(const ConvP& p, int th, int nw, hipStream_t st) {
   constexpr int E = MAU_CONV_TU_EPI;
   constexpr bool F = MAU_CONV_TU_F16 != 0;
   if (p.CoutPad % 128 == 0) return th == 32 ? v2::launch<128, 4, 8, E, F>(p, st) : v2::launch<128, 2, 8, E, F>(p, st);
   if (th == 64) return v2::launch<64, 4, 8, E, F>(p, st);
+  if (th == 32 && nw == 4) return v2::launch<64, 4, 4, E, F>(p, st);
   return th == 32 ? v2::launch<64, 2, 8, E, F>(p, st) : v2::launch<64, 2, 4, E, F>(p, st);
 }
 #else
-int launch_conv_bf16_tu_e0_f0(const ConvP&, int, hipStream_t);
-int launch_conv_bf16_tu_e1_f0(const ConvP&, int, hipStream_t);
-int launch_conv_bf16_tu_e2_f0(const ConvP&, int, hipStream_t);
-int launch_conv_bf16_tu_e0_f1(const ConvP&, int, hipStream_t);
-int launch_conv_bf16_tu_e1_f1(const ConvP&, int, hipStream_t);
-int launch_conv_bf16_tu_e2_f1(const ConvP&, int, hipStream_t);
+int launch_conv_bf16_tu_e0_f0(const ConvP&, int, int, hipStream_t);
+int launch_conv_bf16_tu_e1_f0(const ConvP&, int, int, hipStream_t);
+int launch_conv_bf16_tu_e2_f0(const ConvP&, int, int, hipStream_t);
+int launch_conv_bf16_tu_e0_f1(const ConvP&, int, int, hipStream_t);
+int launch_conv_bf16_tu_e1_f1(const ConvP&, int, int, hipStream_t);
+int launch_conv_bf16_tu_e2_f1(const ConvP&, int, int, hipStream_t);
 
 // rows of the BatchNorm partial-sum slab: one per (pixel tile, wave row of the workgroup)
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   const int CoutPad = round_up(Cout, 64);
   const v2::Variant v = v2::pick_variant(CoutPad, N, H, W);
   const int th = v.th;
-  const int wm = (CoutPad % 128 != 0 && v.nw == 8) ? v2::Geo<64, 2, 8>::WM : 4;    // <128,*,8>, <64,2,4>: 4 wave rows; <64,2,8>, <64,4,8>: 8
+  const int wm = (CoutPad % 128 != 0 && v.nw == 8) ? v2::Geo<64, 2, 8>::WM : 4;    // <128,*,8>, <64,2,4>, <64,4,4>: 4 wave rows; <64,2,8>, <64,4,8>: 8
+  static_assert(v2::Geo<64, 4, 4>::WM == 4 && v2::Geo<64, 4, 4>::TH == 32, "slab rows");
   static_assert(v2::Geo<64, 2, 8>::WM == 8 && v2::Geo<64, 4, 8>::WM == 8 && v2::Geo<64, 4, 8>::TH == 64, "slab rows");
   static_assert(v2::Geo<128, 2, 8>::WM == 4 && v2::Geo<128, 4, 8>::WM == 4 && v2::Geo<64, 2, 4>::WM == 4, "slab rows");
   return wm * N * ceil_div(H, th) * ceil_div(W, v2::TW);
@@ -1043,10 +1057,11 @@ int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
     return MAU_ERR_ARG;
   }
   static_assert(v2::EPI_PLAIN == 0 && v2::EPI_STATS == 1 && v2::EPI_POST == 2, "translation-unit names");
-  const int th = v2::pick_variant(p.CoutPad, p.N, p.H, p.W).th;
-  if (p.post_scale != nullptr) return f16 ? launch_conv_bf16_tu_e2_f1(p, th, st) : launch_conv_bf16_tu_e2_f0(p, th, st);   // (a post-affine launch carries no slab)
-  if (p.slab != nullptr) return f16 ? launch_conv_bf16_tu_e1_f1(p, th, st) : launch_conv_bf16_tu_e1_f0(p, th, st);
-  return f16 ? launch_conv_bf16_tu_e0_f1(p, th, st) : launch_conv_bf16_tu_e0_f0(p, th, st);
+  const v2::Variant v = v2::pick_variant(p.CoutPad, p.N, p.H, p.W);
+  const int th = v.th, nw = v.nw;
+  if (p.post_scale != nullptr) return f16 ? launch_conv_bf16_tu_e2_f1(p, th, nw, st) : launch_conv_bf16_tu_e2_f0(p, th, nw, st);   // (a post-affine launch carries no slab)
+  if (p.slab != nullptr) return f16 ? launch_conv_bf16_tu_e1_f1(p, th, nw, st) : launch_conv_bf16_tu_e1_f0(p, th, nw, st);
+  return f16 ? launch_conv_bf16_tu_e0_f1(p, th, nw, st) : launch_conv_bf16_tu_e0_f0(p, th, nw, st);
 }
 #endif
 

@@ -73,9 +73,12 @@ def _as_nhwc(t: torch.Tensor) -> torch.Tensor:
 
 @dataclass
 class Act:
-    """An internal activation: NHWC-ld tensor + its logical channel count."""
+    """An internal activation: NHWC-ld tensor + its logical channel count.  ``nchw=True``: the network's INPUT as the reference's
+    collate_fn delivers it -- (N, C, H, W) fp32 -- handed to the first convolution untouched (``mau_conv3x3_first_fwd`` reads it
+    directly: no layout kernel)."""
     t: torch.Tensor
     C: int
+    nchw: bool = False
 
     @property
     def N(self):
@@ -83,11 +86,11 @@ class Act:
 
     @property
     def H(self):
-        return self.t.shape[1]
+        return self.t.shape[2 if self.nchw else 1]
 
     @property
     def W(self):
-        return self.t.shape[2]
+        return self.t.shape[3 if self.nchw else 2]
 
 
 # --------------------------------------------------------------------------- #
@@ -300,6 +303,8 @@ class BNState:
     out_view: object = None               # preallocated NHWC-ld view the activation is written into (U-Net++ row buffers)
     head: object = None                   # None | True (tanh on channel 0 when out_channels == 2) | False (bare 1x1): return final(activation)
     up_to: object = None                  # None | (H, W): return the bilinear (align_corners=True) resize of the activation
+    first: bool = False                   # x is the network input (N, C, H, W) fp32, C <= 8: the first-layer kernel reads it as it is
+    dtype: object = None                  # activation dtype of the network (first=True: x itself is fp32)
 
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
@@ -374,11 +379,21 @@ class ConvBNReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x1, emb, weight, bias, gamma, beta, rmean, rvar, nbt, hw, hb, st: BNState):
         _require_cuda(x, "conv3x3")
-        x = _as_nhwc(x)
-        if x1 is not None:
-            x1 = _as_nhwc(x1)
-        N, H, W, _ = x.shape
-        code = dtype_code(x.dtype)
+        first = st.first
+        if first:
+            # the network's first convolution on the input tensor as delivered (src/model.py:222, src/dataset.py:99-106)
+            if x1 is not None or emb is not None or x.dim() != 4 or x.shape[1] != st.C0 or st.C0 > lib.mau_conv3x3_first_max_channels():
+                raise RuntimeError("conv3x3 (first layer): expects one (N, C <= 8, H, W) fp32 input")
+            xin = x.contiguous().float()
+            N, _, H, W = xin.shape
+            act_dt = st.dtype
+        else:
+            x = _as_nhwc(x)
+            if x1 is not None:
+                x1 = _as_nhwc(x1)
+            N, H, W, _ = x.shape
+            act_dt = x.dtype
+        code = dtype_code(act_dt)
         dev = x.device
         Cout, Cin = weight.shape[0], weight.shape[1]
         E = 0 if emb is None else emb.shape[1]
@@ -391,10 +406,10 @@ class ConvBNReLU(torch.autograd.Function):
         stream = _stream()
         needs = ctx.needs_input_grad
         inference = (not st.training) and (not st.grad_enabled or not any(needs))
-        emb_ws = torch.empty((N, E), dtype=x.dtype, device=dev) if E else None
+        emb_ws = torch.empty((N, E), dtype=act_dt, device=dev) if E else None
         f32 = dict(dtype=torch.float32, device=dev)
         dst = st.out_view                               # where the activation goes: a slot of a row buffer, or a fresh tensor
-        if dst is not None and (tuple(dst.shape) != (N, H, W, ldy) or dst.dtype != x.dtype or Cout % 64 != 0):
+        if dst is not None and (tuple(dst.shape) != (N, H, W, ldy) or dst.dtype != act_dt or Cout % 64 != 0):
             raise RuntimeError("conv3x3: out_view must be an (N,H,W,Cout) NHWC-ld view of the activation dtype with Cout % 64 == 0")
         if sum((st.pool, st.head is not None, st.up_to is not None)) > 1 or ((st.head is not None or st.up_to is not None) and dst is not None):
             raise RuntimeError("conv3x3: pool / head / up_to are exclusive, and head / up_to write no activation (no out_view)")
@@ -405,8 +420,15 @@ class ConvBNReLU(torch.autograd.Function):
             tanh0 = 1 if (Co == 2 and st.head) else 0
             w2 = hw.detach().reshape(Co, Cout).contiguous().float()
 
+        def first_fwd(post, y_, slab_, x8_):
+            """conv0_0.conv1 straight from the fp32 NCHW input and the fp32 master weights (no layout kernel, no weight pack)"""
+            scale_, shift_ = post if post is not None else (None, None)
+            call("mau_conv3x3_first_fwd", xin.data_ptr(), st.C0, weight.detach().data_ptr(), bias.detach().data_ptr() if bias is not None else None,
+                 scale_.data_ptr() if scale_ is not None else None, shift_.data_ptr() if shift_ is not None else None, y_.data_ptr(), _ld(y_),
+                 Cout, slab_.data_ptr() if slab_ is not None else None, x8_.data_ptr() if x8_ is not None else None, code, N, H, W, stream)
+
         def pooled_of(a):
-            pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
+            pl = torch.empty((N, H // 2, W // 2, ldy), dtype=act_dt, device=dev)
             call("mau_maxpool2x2_fwd", a.data_ptr(), _ld(a), pl.data_ptr(), ldy, code, N, H, W, Cout, stream)
             return pl
 
@@ -418,28 +440,31 @@ class ConvBNReLU(torch.autograd.Function):
 
         def up_of(a):                                   # bilinear resize of a materialised activation
             Hu, Wu = st.up_to
-            up = torch.empty((N, Hu, Wu, ldy), dtype=x.dtype, device=dev)
+            up = torch.empty((N, Hu, Wu, ldy), dtype=act_dt, device=dev)
             call("mau_resize_bilinear_fwd", a.data_ptr(), _ld(a), H, W, up.data_ptr(), ldy, 0, code, N, Hu, Wu, Cout, stream)
             return up
 
         if inference:
             # eval-mode BN + ReLU are a fixed per-channel affine map -> folded into the conv epilogue.  In a frozen
             # session (UrbanPredictor.freeze_inference) the packed weights and the folded coefficients are computed once.
-            y = dst if dst is not None else torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
+            y = dst if dst is not None else torch.empty((N, H, W, ldy), dtype=act_dt, device=dev)
             fz = st.frozen if st.frozen is not None else {}
             fkey = (_GENERATION[0], weight._version, gamma._version, rmean._version, rvar._version)
-            if "wf" not in fz or fz["wf"].dtype != x.dtype or fz.get("key") != fkey:
+            if "wf" not in fz or fz["wf"].dtype != act_dt or fz.get("key") != fkey:
                 # (an optimizer step -- of ANY model: the generation counter is global --, mark_params_updated() or an in-place
                 #  write re-derives the copies.)  Everything is refreshed IN PLACE: the packs are persistent buffers and
                 # scale / shift are allocated once per session, so a live GraphedInference graph, which holds these
                 # addresses, replays with the new values instead of reading freed memory.
                 fz["key"] = fkey
-                fz["wf"] = pack_conv_weights(weight, code, forward=True, dgrad=False)[0]
+                fz["wf"] = weight if first else pack_conv_weights(weight, code, forward=True, dgrad=False)[0]     # (first layer: the master weights themselves)
                 if "scale" not in fz or fz["scale"].device != dev or fz["scale"].numel() != Cout:
                     fz["scale"], fz["shift"] = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
                 call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                      st.eps, fz["scale"].data_ptr(), fz["shift"].data_ptr(), None, None, Cout, stream)
-            _conv_fwd(x, x1, st, emb, emb_ws, E, fz["wf"], bias, (fz["scale"], fz["shift"]), y, Cout, None, code, N, H, W, stream)
+            if first:
+                first_fwd((fz["scale"], fz["shift"]), y, None, None)
+            else:
+                _conv_fwd(x, x1, st, emb, emb_ws, E, fz["wf"], bias, (fz["scale"], fz["shift"]), y, Cout, None, code, N, H, W, stream)
             if st.head is not None:
                 out = head_of(y)
                 ctx.mark_non_differentiable(out)
@@ -454,17 +479,27 @@ class ConvBNReLU(torch.autograd.Function):
                 ctx.mark_non_differentiable(pl)
                 return y, pl
             return y
-        y = torch.empty((N, H, W, ldy), dtype=x.dtype, device=dev)
+        y = torch.empty((N, H, W, ldy), dtype=act_dt, device=dev)
         need_dx = needs[0] or (x1 is not None and needs[1]) or (E > 0 and needs[2])
-        wf, wd = pack_conv_weights(weight, code, forward=True, dgrad=st.grad_enabled and need_dx)
+        if first:
+            if need_dx:
+                raise RuntimeError("conv3x3 (first layer): no gradient w.r.t. the network input on this path")
+            wf = wd = None
+            # the input in the activation type as NHWC-8: what this layer's weight gradient reads; a by-product of the same pass
+            x = torch.empty((N, H, W, 8), dtype=act_dt, device=dev) if (st.grad_enabled and needs[3]) else None
+        else:
+            wf, wd = pack_conv_weights(weight, code, forward=True, dgrad=st.grad_enabled and need_dx)
         scale, shift = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
         mean, invstd = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
         npix = N * H * W
         if st.training:
-            tiles = lib.mau_conv3x3_num_pixel_tiles(code, N, H, W, Cout)
+            tiles = lib.mau_conv3x3_first_rows(N, H, W) if first else lib.mau_conv3x3_num_pixel_tiles(code, N, H, W, Cout)
             cpad = (Cout + 63) // 64 * 64
             slab = torch.empty((tiles, 2 * cpad), **f32)
-            _conv_fwd(x, x1, st, emb, emb_ws, E, wf, bias, None, y, Cout, slab, code, N, H, W, stream)
+            if first:
+                first_fwd(None, y, slab, x)
+            else:
+                _conv_fwd(x, x1, st, emb, emb_ws, E, wf, bias, None, y, Cout, slab, code, N, H, W, stream)
             nbt_ptr = nbt.data_ptr() if nbt is not None else None
             tk = _tickets(dev).data_ptr() if _FUSED_REDUCE else None
             if st.group is None:
@@ -487,7 +522,10 @@ class ConvBNReLU(torch.autograd.Function):
         else:
             call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                  st.eps, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), Cout, stream)
-            _conv_fwd(x, x1, st, emb, emb_ws, E, wf, bias, None, y, Cout, None, code, N, H, W, stream)
+            if first:
+                first_fwd(None, y, None, x)
+            else:
+                _conv_fwd(x, x1, st, emb, emb_ws, E, wf, bias, None, y, Cout, None, code, N, H, W, stream)
 
         # ---- the activation stage ----
         fused = _FUSED_BN
@@ -500,14 +538,14 @@ class ConvBNReLU(torch.autograd.Function):
                  out.data_ptr(), tanh0, code, N, H * W, Cout, Co, stream)
         elif fuse_up:                                    # the resize applies BatchNorm + ReLU to the corners it loads
             Hu, Wu = st.up_to
-            up = torch.empty((N, Hu, Wu, ldy), dtype=x.dtype, device=dev)
+            up = torch.empty((N, Hu, Wu, ldy), dtype=act_dt, device=dev)
             call("mau_resize_bilinear_bn_fwd", y.data_ptr(), ldy, H, W, scale.data_ptr(), shift.data_ptr(), up.data_ptr(), ldy, 0, code,
                  N, Hu, Wu, Cout, stream)
         else:
             a = dst if dst is not None else torch.empty_like(y)
             lda = _ld(a)
             if st.pool and H >= 2 and W >= 2:
-                pl = torch.empty((N, H // 2, W // 2, ldy), dtype=x.dtype, device=dev)
+                pl = torch.empty((N, H // 2, W // 2, ldy), dtype=act_dt, device=dev)
                 # 2 bits per (window, channel): which pixel holds the maximum -- the routing of the pool's backward (fused with the
                 # BatchNorm backward passes, no activation is re-read for it)
                 argidx = torch.empty((N, H // 2, W // 2, ldy // 8), dtype=torch.int16, device=dev) if fused else None

@@ -87,7 +87,7 @@ class VGGBlock(nn.Module):
                      group=rt.group, comm=rt.comm, world=rt.world, grad_enabled=torch.is_grad_enabled(),
                      frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1],
                      C1=0 if x1 is None else x1.C, pool=pool, out_view=out_view,
-                     head=None if head is None else bool(head_act), up_to=up_to)
+                     head=None if head is None else bool(head_act), up_to=up_to, first=x.nchw, dtype=rt.dtype if x.nchw else None)
         # (``weight``: a tensor DERIVED from conv.weight that the convolution runs on instead -- functional.EmbFold's W_eff)
         t = F_.ConvBNReLU.apply(x.t, None if x1 is None else x1.t, emb, conv.weight if weight is None else weight, conv.bias, bn.weight, bn.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked,
@@ -117,7 +117,7 @@ class VGGBlock(nn.Module):
         output is written into (a slot of a U-Net++ row buffer); ``head``: the network's final 1x1 conv -- the block returns
         ``final(block output)`` (tanh on channel 0 when ``head_act`` and out_channels == 2) and the block output itself is never
         written; ``up_to=(H, W)``: the block returns the bilinear (align_corners=True) resize of its output instead of it."""
-        emb, w1 = self._fold(emb, x.C + (0 if x1 is None else x1.C), x.H * x.W, x.t.dtype)
+        emb, w1 = self._fold(emb, x.C + (0 if x1 is None else x1.C), x.H * x.W, torch.float32 if x.nchw else x.t.dtype)
         x = self._half(x, emb, self.conv1, self.bn1, x1, weight=w1)
         return self._half(x, None, self.conv2, self.bn2, None, pool, out_view, head, head_act, up_to)
 
@@ -263,6 +263,12 @@ class _NetBase(nn.Module):
             if maps.t.dtype != self._rt.dtype:
                 raise RuntimeError(f"packed input is {maps.t.dtype}, the network computes in {self._rt.dtype}")
             return maps
+        # 16-bit modes, at most 8 input channels (BASELINE configs: 6), no gradient w.r.t. the input: the first convolution reads the
+        # tensor as it is (mau_conv3x3_first_fwd) -- no NCHW -> NHWC layout kernel, no packed copy of its weights.  MAU_CONV_FIRST=0: A/B.
+        if (self._rt.dtype != torch.float32 and maps.dim() == 4 and maps.shape[1] <= F_.lib.mau_conv3x3_first_max_channels()
+                and not (maps.requires_grad and torch.is_grad_enabled()) and os.environ.get("MAU_CONV_FIRST", "1") != "0"):
+            F_._require_cuda(maps, "UrbanPredictor.forward(maps)")
+            return Act(maps, maps.shape[1], nchw=True)
         return Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
 
     def _block_pool(self, block: VGGBlock, x: Act, out_view=None):
@@ -481,7 +487,7 @@ class UrbanPredictor_unetpp(_NetBase):
         # The buffers are written by raw kernels through ``BNState.out_view`` and read through views: no torch in-place op may
         # ever touch them (it would bump the version counter autograd checks for the saved slots).
         use_rows = self._rt.dtype != torch.float32 and nb0 % 64 == 0 and os.environ.get("MAU_VIRTUAL_CONCAT", "1") != "0"
-        N, H, W = x.t.shape[0], x.t.shape[1], x.t.shape[2]
+        N, H, W = x.N, x.H, x.W
         hs, ws = [H], [W]
         for _ in range(3):
             hs.append(hs[-1] // 2)

@@ -13,7 +13,7 @@ for spec in "$@"; do
     if [ "$SRC" == "conv3x3_bf16.hip" ]; then parts="conv3x3_bf16 conv3x3_bf16_e0_bf16 conv3x3_bf16_e1_bf16 conv3x3_bf16_e2_bf16 conv3x3_bf16_e0_f16 conv3x3_bf16_e1_f16 conv3x3_bf16_e2_f16"; else parts="${SRC%.hip}"; fi
     for part in $parts; do /opt/rocm/bin/hipcc $FLAGS $defs -c $part.hip -o ../variants/${part}_$name.o & done; wait
     objs=""
-    for f in capi conv3x3 conv3x3_bf16 conv3x3_bf16_e0_bf16 conv3x3_bf16_e1_bf16 conv3x3_bf16_e2_bf16 conv3x3_bf16_e0_f16 conv3x3_bf16_e1_f16 conv3x3_bf16_e2_f16 conv3x3_wgrad_bf16 conv3x3_wgrad16 bn bn_fused spatial head lstm ssim optim embfold; do
+    for f in capi conv3x3 conv3x3_bf16 conv3x3_bf16_e0_bf16 conv3x3_bf16_e1_bf16 conv3x3_bf16_e2_bf16 conv3x3_bf16_e0_f16 conv3x3_bf16_e1_f16 conv3x3_bf16_e2_f16 conv3x3_wgrad_bf16 conv3x3_wgrad16 conv3x3_first bn bn_fused spatial head lstm ssim optim embfold; do
       [ -f $f.hip ] || continue
       if [[ " $parts " == *" $f "* ]]; then objs="$objs ../variants/${f}_$name.o"; else objs="$objs $f.o"; fi
     done
