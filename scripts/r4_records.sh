@@ -1,0 +1,33 @@
+#!/bin/bash
+# round-4 records on ONE box.  Through gpurun; outputs -> gpurun_out/rec4/
+set -u
+export TMPDIR=/tmp
+R=gpurun_out/rec4; mkdir -p $R
+# 1. rocprofv3 passes of the headline workload (eager launches: a hipGraph replay is one dispatch to the profiler)
+bash scripts/profile.sh r4 --no-graph --repeats 1
+python scripts/summarize_profile.py gpurun_out/prof_r4 gpurun_out/r4_profiles unet_bf16_b32_s256_c6_train > $R/profiles_summ.txt 2>&1; echo "summ rc=$?"
+mkdir -p profiles/r4 && cp gpurun_out/r4_profiles/pmc_summary.json profiles/r4/pmc_summary.json     # bench.py below reads this round's PMC record (same libmau_hip.so)
+# 2. bench lines of every BASELINE config
+jl() { python scripts/json_only.py; }
+python bench.py 2>> $R/err.txt | jl > $R/bench_default.json; echo "default rc=$?"
+python bench.py --no-cpu-baseline --no-graph 2>> $R/err.txt | jl > $R/bench_default_eager.json
+MAU_DP_GRAPH=0 python bench.py --no-cpu-baseline --force-dist 2>> $R/err.txt | jl > $R/bench_dp1_forced_eager.json
+MAU_DP_GRAPH=1 python bench.py --no-cpu-baseline --force-dist 2>> $R/err.txt | jl > $R/bench_dp1_forced_graph.json
+python bench.py --no-cpu-baseline --model-type unet++ --batch 16 2>> $R/err.txt | jl > $R/bench_unetpp_b16.json
+python bench.py --no-cpu-baseline --model-type unet++ --batch 16 --seq-len 828 2>> $R/err.txt | jl > $R/bench_unetpp_b16_T828.json
+python bench.py --no-cpu-baseline --infer --size 512 --batch 8 --precision fp16 2>> $R/err.txt | jl > $R/bench_infer512_fp16.json
+python bench.py --no-cpu-baseline --infer --size 512 --batch 8 --precision bf16 2>> $R/err.txt | jl > $R/bench_infer512_bf16_b8.json
+python bench.py --no-cpu-baseline --infer --size 512 --batch 1 --channels 23 --meta 8 --precision fp16 2>> $R/err.txt | jl > $R/bench_infer512_fp16_b1_c23.json
+python bench.py --no-cpu-baseline --precision fp32 --batch 8 2>> $R/err.txt | jl > $R/bench_fp32_b8.json
+echo "bench lines done"
+# 3. per-layer timing and per-layer HBM traffic of the convolution kernels
+OUT=$R/conv_layers.json timeout -k 10 300 python scripts/conv_layer_bench.py > $R/conv_layers.txt 2>&1; echo "layers rc=$?"
+mkdir -p gpurun_out/layer_pmc
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/layer_pmc/pmc_fetch -- python3 scripts/conv_layer_bench.py > gpurun_out/layer_pmc/fetch.log 2>&1; echo "layer fetch rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/layer_pmc/pmc_write -- python3 scripts/conv_layer_bench.py > gpurun_out/layer_pmc/write.log 2>&1; echo "layer write rc=$?"
+python scripts/layer_traffic.py gpurun_out/layer_pmc $R/layer_traffic.json > $R/layer_traffic.txt 2>&1; echo "traffic rc=$?"; tail -4 $R/layer_traffic.txt
+# 4. one-step kernel traces
+bash scripts/r4_trace.sh unet > /dev/null 2>&1; cp gpurun_out/r4_trace_unet/step.txt $R/step_trace.txt
+bash scripts/r4_trace.sh upp --model-type unet++ --batch 16 > /dev/null 2>&1; cp gpurun_out/r4_trace_upp/step.txt $R/step_trace_unetpp.txt
+timeout -k 10 120 python scripts/first_layer_bench.py > $R/first_layer.txt 2>&1; echo "first rc=$?"
+timeout -k 10 120 python scripts/fused_bn_bench.py > $R/fused_bn.txt 2>&1; echo "fused rc=$?"
