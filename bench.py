@@ -52,6 +52,7 @@ class ConvTimer:
         self.F_ = F_
         self.records = []
         self.wrecords = []
+        self.urecords = []          # mau_conv3x3_unpack_wgrad: the weight gradient's second stage (split-K sum + un-tiling)
         self.enabled = False
         self._orig = F_.call
 
@@ -86,6 +87,15 @@ class ConvTimer:
                 # algorithmic bytes of the launch: X and dY read once (16-bit), dW written once (fp32)
                 self.wbytes = getattr(self, "wbytes", 0.0) + (Cin + Cout) * N * H * W * 2.0 + 9.0 * Cin * Cout * 4.0
                 self.wrecords.append((e0, e1, conv_flops(N, H, W, Cin, Cout)))
+            elif self.enabled and name == "mau_conv3x3_unpack_wgrad":
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                cur = torch.cuda.current_stream()
+                ws = cur if args[-1] == cur.cuda_stream else torch.cuda.ExternalStream(args[-1])
+                e0.record(ws)
+                orig(name, *args)
+                e1.record(ws)
+                self.urecords.append((e0, e1, 0.0))
             else:
                 orig(name, *args)
 
@@ -108,7 +118,10 @@ class ConvTimer:
         return r
 
     def wgrad_summary(self):
-        return self._sum(self.wrecords)
+        r = self._sum(self.wrecords)
+        if r is not None and self.urecords:
+            r["unpack_ms"] = sum(a.elapsed_time(b) for a, b, _ in self.urecords)
+        return r
 
 
 def cpu_baseline(iters=5, warmup=2):
@@ -616,7 +629,10 @@ def main():
                              "launches": wg["launches"], "avg_launch_ms": round(wg["total_ms"] / wg["launches"], 4),
                              "traffic": wrec.get("hbm_bytes_per_launch_pmc"), "algorithmic_bytes": round(timer.wbytes / wg["launches"]),
                              "traffic_ratio": round(wrec["hbm_bytes_per_launch_pmc"] / (timer.wbytes / wg["launches"]), 3) if wrec.get("hbm_bytes_per_launch_pmc") else None,
-                             "mfma_busy": wrec.get("mfma_busy_long"), "clock_ghz": wrec.get("clock_ghz_long"), "flop_per_launch_avg": wflop}
+                             "mfma_busy": wrec.get("mfma_busy_long"), "clock_ghz": wrec.get("clock_ghz_long"), "flop_per_launch_avg": wflop,
+                             # the second stage (mau_conv3x3_unpack_wgrad: fixed-order split-K sum + un-tiling into the gradient arena) counted in
+                             "unpack_ms_per_step": round(wg.get("unpack_ms", 0.0) / args.steps, 4),
+                             "frac_with_unpack": round(wg["total_flop"] / ((wg["total_ms"] + wg.get("unpack_ms", 0.0)) * 1e-3) / 1e12 / peak, 4)}
     result = {
         "metric": ("inference images/sec" if args.infer else "train images/sec") + f" ({S}x{S}x{args.channels}->2 {'U-Net' if args.model_type == 'unet' else 'U-Net++'}, B={B}/GPU)",
         "value": round(B * world * args.steps / elapsed, 2),
