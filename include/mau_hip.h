@@ -107,6 +107,13 @@ int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout);
  * weight gradient of this layer reads (mau_conv3x3_wgrad2 with ldx = 8); written from the same pass over x. */
 int mau_conv3x3_first_max_channels(void);
 int mau_conv3x3_first_rows(int N, int H, int W);
+/* The same layer's weight gradient (autograd's conv weight gradient of conv0_0.conv1, src/train.py:252 with src/model.py:12,222):
+ * dw (Cout,Cin,3,3) fp32 = sum over pixels of dz (x) x, complete (no second call), bitwise reproducible.  x8 = the NHWC-8 copy of the
+ * input written by mau_conv3x3_first_fwd; dz (N,H,W,lddz) the gradient w.r.t. the convolution's output in `dtype`; ws = workspace of
+ * mau_conv3x3_first_wgrad_ws_elems(N,H,W,Cout) floats (one compact slab per persistent workgroup).  Cin <= 8, 16-bit types. */
+size_t mau_conv3x3_first_wgrad_ws_elems(int N, int H, int W, int Cout);
+int mau_conv3x3_first_wgrad(const void* x8, const void* dz, int lddz, float* dw_oihw, float* ws, int Cin, int Cout, int dtype, int N,
+                            int H, int W, mau_stream_t stream);
 int mau_conv3x3_first_fwd(const float* x_nchw, int Cin, const float* w_oihw, const float* bias, const float* post_scale,
                           const float* post_shift, void* y, int ldy, int Cout, float* slab, void* x8, int dtype, int N, int H,
                           int W, mau_stream_t stream);

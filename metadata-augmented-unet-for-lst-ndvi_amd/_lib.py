@@ -41,6 +41,8 @@ PROTOTYPES = {
     "mau_conv3x3_num_pixel_tiles": (_i, [_i, _i, _i, _i, _i]),
     "mau_conv3x3_first_max_channels": (_i, []),
     "mau_conv3x3_first_rows": (_i, [_i, _i, _i]),
+    "mau_conv3x3_first_wgrad_ws_elems": (_sz, [_i, _i, _i, _i]),
+    "mau_conv3x3_first_wgrad": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_conv3x3_first_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_fwd": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_fwd2": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),

@@ -370,3 +370,249 @@ int mau_conv3x3_first_fwd(const float* x, int Cin, const float* w, const float* 
 }
 
 }  // extern "C"
+
+// ======================================================================================================================
+// The first layer's WEIGHT GRADIENT:  dW[co][ci][tap] = sum over pixels  dZ[pix][co] * X[pix + tap][ci],  Cin <= 8.
+// (autograd's conv weight gradient of conv0_0.conv1 under loss.backward(), reference src/train.py:252 / src/model.py:12,222)
+//
+// 14.5 GFLOP against 302 MB of reads (dZ: 268 MB, X as the forward's NHWC-8 by-product: 34 MB): pure HBM work, 50 us at 6 TB/s.
+// The generic weight-gradient kernel (64 input channels per workgroup, 30 halo DMAs of mostly padding per stage, three of four
+// waves multiplying zeros) needs 117 us.  Here the GEMM is  D[co (64)][n = (tap, ci): six column tiles of 16]  with K = pixels:
+//   * a WAVE owns a stream of (row, 32-pixel segment) tiles and two private LDS buffers: no workgroup barrier in the loop, and no
+//     global store before the end -- so "my DMAs have landed" is a counted vmcnt, never a wait behind stores (the first-layer
+//     forward kernel's lesson, DESIGN.md "Round 4")
+//   * per tile 7 wave-DMAs (LDS-DMA; out-of-image lanes read a zero page = the padding): the dZ row segment
+//     [32 px][64 co] (4 KB) and three X halo rows [34 px][8 ci] (16 bytes per pixel)
+//   * one K = 32 step of v_mfma_f32_16x16x32 per tile: A = dZ^T (4 co tiles), B = the im2col of X, both through ds_read_b64_tr_b16.
+//     A B tile's 16 columns are the 32 CONTIGUOUS bytes at (halo row dy, pixel + dx): the 8 channels of tap (dy, dx) and of its right
+//     neighbour (dy, dx + 1).  (A transposed read wants the four lanes of a block row on one contiguous 32-byte run: a tile made of
+//     taps (0,2) and (1,0) -- two rows of the halo -- returned wrong columns.)  Six tiles: (dy, dx = 0 | 1) and (dy, dx = 2 | junk)
+//     per halo row; the junk halves are never summed
+//   * 96 accumulator registers; the four waves of a workgroup add up through LDS (fixed order), one compact slab
+//     [workgroup][64][80] fp32, a second kernel adds the slabs in workgroup order and writes OIHW: bitwise reproducible
+namespace mau {
+namespace firstw {
+using namespace igemm;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TWW = 32;                       // pixels per tile (one K step)
+constexpr int DZ_BYTES = TWW * 128;           // [32 px][64 co] 16-bit
+constexpr int XROW = 1024;                    // one halo row: 34 pixels x 16 B, padded to a whole wave-DMA
+constexpr int BUF = DZ_BYTES + 3 * XROW;      // 7168
+constexpr int NT = 256, NWAVE = 4, NDMA = 7;
+constexpr int NBT = 6, NCOL = 16 * NBT;       // column tiles: per halo row dy one for taps (dy,0),(dy,1) and one for (dy,2),(junk)
+
+struct WP {
+  const void* x8;
+  const void* dz;
+  int lddz, Cout;
+  float* ws;           // [gridDim.x][gridDim.y * 64][NCOL]
+  int N, H, W, tilesX, nTiles;
+};
+
+template <bool F16>
+__device__ __forceinline__ void mfma(const u32x4& a, const u32x4& b, f32x4v& c) {
+  if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// 4 rows x 16 columns of 16-bit elements, delivered column-major: lane 4q + p of a 16-lane group supplies the address of row q,
+// columns 4p .. 4p+3; lane i receives column i of the four rows.  Two of them (rows 0-3 | 4-7 of a lane group's 8 pixels) = one fragment.
+template <int OFF_HI>
+__device__ __forceinline__ u32x4 tr_frag(unsigned addr_lo, unsigned addr_hi) {
+  u32x2 lo, hi;
+  // (early-clobber outputs: without '&' the compiler may give the first read's destination the address register the second read still
+  //  needs -- `ds_read_b64_tr_b16 v[114:115], v114` followed by `ds_read_b64_tr_b16 v[116:117], v114 offset:512` -- which works only
+  //  while the first read's data has not come back when the second issues: sporadically wrong with two waves per SIMD)
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(addr_lo), "v"(addr_hi), "n"(OFF_HI));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
+template <bool F16>
+__global__ __launch_bounds__(NT, 2) void first_wgrad_kernel(WP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // NWAVE x 2 x BUF, later the cross-wave sum
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int co0 = blockIdx.y * 64;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + wave * (2 * BUF);
+  // Out-of-image lanes read 16 zero bytes of global memory (g_zero_page) through a per-lane 64-bit address.  (The big convolution kernels
+  // use the buffer-addressed form -- offset -1, zeros from the hardware range check -- for lanes at the image border; here WHOLE
+  // wave-DMAs fall outside the image (a halo row above / below it, the tail of a ragged row segment), a case those kernels never
+  // produce and this one does not want to depend on; seven address computations per 32 pixels cost nothing.)
+  const unsigned long long dz_a = (unsigned long long)p.dz, x_a = (unsigned long long)p.x8, zero_a = (unsigned long long)g_zero_page;
+
+  // per-lane constants of the DMAs: dZ DMA d (0..3) covers pixels 8d .. 8d+7, lane = (pixel % 8) * 8 + 16-byte chunk; X halo DMA: lane = halo column
+  const int dz_px = lane >> 3, dz_ch = lane & 7;
+  const bool dz_ch_ok = co0 + 8 * dz_ch < p.lddz;                          // (narrow layers: the row holds fewer than 64 channels)
+  auto issue = [&](int tile, int buf) {
+    const int txi = tile % p.tilesX, rowi = tile / p.tilesX;               // rowi = n * H + y
+    const int x0 = txi * TWW, y = rowi % p.H;
+    unsigned char* dst = smem + wave * (2 * BUF) + buf * BUF;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int gx = x0 + 8 * d + dz_px;
+      unsigned long long src = dz_a + 2ull * ((unsigned long long)((long long)rowi * p.W + gx) * (unsigned)p.lddz + (unsigned)(co0 + 8 * dz_ch));
+      asm volatile("" : "+v"(src));                      // (both candidates materialised: no exec-masked branch around the 64-bit multiply)
+      src = (gx < p.W && dz_ch_ok) ? src : zero_a;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(dst + d * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int gy = y + dy - 1, gx = x0 + lane - 1;
+      const bool in = lane < TWW + 2 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      unsigned long long src = x_a + 16ull * (unsigned long long)((long long)(rowi + dy - 1) * p.W + gx);
+      asm volatile("" : "+v"(src));
+      src = in ? src : zero_a;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(dst + DZ_BYTES + dy * XROW), 16, 0, 0);
+    }
+  };
+  // per-lane LDS read addresses (relative to a buffer).  Lane l: K block g = l / 16 (pixels 8g .. 8g+7), i = l % 16 -> row q = i / 4 of
+  // the 4-pixel block, column quad pq = i % 4.
+  const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+  //   A (co tile t): pixel 8g + q (+4), channels 16t + 4pq .. +3
+  const unsigned a_lane = (unsigned)((8 * g + q) * 128 + 8 * pq);
+  //   B (column tile j): halo row dy = j / 2, first tap dx = 2 (j % 2): the 32 bytes at halo pixel 8g + q (+4) + dx = that tap's 8 channels
+  //   and the next pixel's (tap dx + 1; for dx = 2 a pixel that is no tap: columns nobody sums); the lane takes bytes 8 pq .. 8 pq + 7
+  unsigned b_lane[NBT];
+#pragma unroll
+  for (int j = 0; j < NBT; ++j) b_lane[j] = (unsigned)(DZ_BYTES + (j >> 1) * XROW + (8 * g + q + 2 * (j & 1)) * 16 + 8 * pq);
+  f32x4v acc[4][NBT];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) acc[t][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  const int nw = gridDim.x * NWAVE, w0 = blockIdx.x * NWAVE + wave;
+  int buf = 0;
+  if (w0 < p.nTiles) issue(w0, 0);
+  for (int tile = w0; tile < p.nTiles; tile += nw) {
+    const bool more = tile + nw < p.nTiles;
+    if (more) {
+      issue(tile + nw, buf ^ 1);
+      wait_vmcnt<NDMA>();                                // the NDMA just issued may be in flight; this tile's have landed
+    } else {
+      wait_vmcnt<0>();
+    }
+    const unsigned base = lds0 + buf * BUF;
+    u32x4 A[4], B[NBT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) A[t] = tr_frag<4 * 128>(base + a_lane + 32 * t, base + a_lane + 32 * t);
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) B[j] = tr_frag<4 * 16>(base + b_lane[j], base + b_lane[j]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < NBT; ++j) mfma<F16>(A[t], B[j], acc[t][j]);
+    // (the fragments are in registers: the buffer may be refilled by the DMAs issued at the top of the next trip)
+    buf ^= 1;
+  }
+  wait_vmcnt<0>();
+  // ---- the four waves' sums, in wave order, through LDS; D layout: column n = lane % 16 of tile j, rows 4 (lane / 16) + r of tile t ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);            // [64 co][NCOL] = 24 KB <= NWAVE * 2 * BUF
+  const int dn = lane & 15, dq = lane >> 4;
+  for (int wv = 0; wv < NWAVE; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < NBT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* e = red + (16 * t + 4 * dq + r) * NCOL + 16 * j + dn;
+            *e = wv == 0 ? acc[t][j][r] : *e + acc[t][j][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* out = p.ws + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64 * NCOL;
+  for (int i = tid; i < 64 * NCOL; i += NT) out[i] = red[i];
+}
+
+// ws [nwg][coTiles * 64][NCOL] -> dw (Cout, Cin, 3, 3).  A workgroup = 32 output elements x 8 slices: slice s adds the workgroups'
+// slabs s, s + 8, s + 16, ... (8 loads in flight per thread), the slices meet in LDS and are added in slice order: a fixed tree.
+constexpr int SUM_SL = 8, SUM_EL = 32;
+__global__ __launch_bounds__(SUM_SL * SUM_EL) void first_wgrad_sum_kernel(const float* __restrict__ ws, int nwg, int coTiles, float* __restrict__ dw, int Cout, int Cin) {
+  __shared__ float part[SUM_SL][SUM_EL];
+  const int el = threadIdx.x % SUM_EL, sl = threadIdx.x / SUM_EL;
+  const int i = blockIdx.x * SUM_EL + el, total = Cout * Cin * 9;
+  const int ic = i < total ? i : 0;
+  const int tap = ic % 9, ci = (ic / 9) % Cin, co = ic / (9 * Cin);
+  const int dy = tap / 3, dx = tap - 3 * dy;
+  const int col = 16 * (2 * dy + (dx == 2)) + 8 * (dx == 1) + ci;              // column tile (dy, dx = 0|1) or (dy, dx = 2), half, channel
+  const float* src = ws + (size_t)co * NCOL + col;
+  const size_t stride = (size_t)coTiles * 64 * NCOL;
+  float s = 0.f;
+  int wgi = sl;
+  for (; wgi + 7 * SUM_SL < nwg; wgi += 8 * SUM_SL) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(wgi + u * SUM_SL) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; wgi < nwg; wgi += SUM_SL) s += src[(size_t)wgi * stride];
+  part[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && i < total) {
+    float o = part[0][el];
+#pragma unroll
+    for (int k = 1; k < SUM_SL; ++k) o += part[k][el];
+    dw[i] = o;
+  }
+}
+
+static int grid_x(int nTiles) {
+  const int cap = device_shape().cus * 2;                // two 4-wave workgroups (2 x 56 KB of LDS) per CU
+  const int need = ceil_div(nTiles, NWAVE);
+  return need < cap ? need : cap;
+}
+}  // namespace firstw
+}  // namespace mau
+
+extern "C" {
+
+size_t mau_conv3x3_first_wgrad_ws_elems(int N, int H, int W, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  return (size_t)mau::firstw::grid_x(N * H * mau::ceil_div(W, mau::firstw::TWW)) * mau::round_up(Cout, 64) * mau::firstw::NCOL;
+}
+
+int mau_conv3x3_first_wgrad(const void* x8, const void* dz, int lddz, float* dw, float* ws, int Cin, int Cout, int dtype, int N, int H, int W,
+                            mau_stream_t stream) {
+  using namespace mau;
+  MAU_REQUIRE(x8 && dz && dw && ws && N > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_first_wgrad: bad arguments");
+  MAU_REQUIRE(Cin >= 1 && Cin <= 8, "conv3x3_first_wgrad: %d input channels (this kernel serves <= 8; use mau_conv3x3_wgrad2)", Cin);
+  MAU_REQUIRE(dtype == MAU_BF16 || dtype == MAU_F16, "conv3x3_first_wgrad: 16-bit activation types only");
+  MAU_REQUIRE(lddz % 8 == 0 && lddz >= Cout && ((uintptr_t)x8 % 16) == 0 && ((uintptr_t)dz % 16) == 0, "conv3x3_first_wgrad: bad lddz / alignment");
+  firstw::WP p;
+  p.x8 = x8;
+  p.dz = dz;
+  p.lddz = lddz;
+  p.Cout = Cout;
+  p.ws = ws;
+  p.N = N;
+  p.H = H;
+  p.W = W;
+  p.tilesX = ceil_div(W, firstw::TWW);
+  p.nTiles = N * H * p.tilesX;
+  const int coTiles = round_up(Cout, 64) / 64;
+  const dim3 grid(firstw::grid_x(p.nTiles), coTiles);
+  constexpr size_t lds = (size_t)firstw::NWAVE * 2 * firstw::BUF;
+  static_assert(lds >= 64 * firstw::NCOL * sizeof(float), "the cross-wave sum fits the DMA buffers");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MAU_F16) {
+    MAU_LDS_ATTR(lds, &firstw::first_wgrad_kernel<true>);
+    MAU_LAUNCH(firstw::first_wgrad_kernel<true>, grid, dim3(firstw::NT), lds, st, p);
+  } else {
+    MAU_LDS_ATTR(lds, &firstw::first_wgrad_kernel<false>);
+    MAU_LAUNCH(firstw::first_wgrad_kernel<false>, grid, dim3(firstw::NT), lds, st, p);
+  }
+  const int rc = check_launch("first_wgrad_kernel");
+  if (rc != MAU_OK) return rc;
+  MAU_LAUNCH(firstw::first_wgrad_sum_kernel, dim3(ceil_div(Cout * Cin * 9, firstw::SUM_EL)), dim3(firstw::SUM_SL * firstw::SUM_EL), 0, st, ws, (int)grid.x,
+             coTiles, dw, Cout, Cin);
+  return check_launch("first_wgrad_sum_kernel");
+}
+
+}  // extern "C"

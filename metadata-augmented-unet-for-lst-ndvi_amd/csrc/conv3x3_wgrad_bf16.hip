@@ -68,7 +68,7 @@ __device__ __forceinline__ void tr_read(Frag& f, unsigned addr) {
   static_assert(OFF >= 0 && OFF + HI < 65536, "ds offset field");
   u32x2 lo, hi;
   asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-               : "=v"(lo), "=v"(hi)
+               : "=&v"(lo), "=&v"(hi)       // early-clobber: the second read still needs the address register (conv3x3_first.hip tr_frag)
                : "v"(addr), "n"(OFF), "n"(OFF + HI));
   f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }

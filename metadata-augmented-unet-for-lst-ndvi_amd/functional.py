@@ -331,6 +331,7 @@ _OVERLAP_WGRAD = int(os.environ.get("MAU_OVERLAP_WGRAD", "2") or 0)
 _FUSED_REDUCE = os.environ.get("MAU_FUSED_REDUCE", "1") != "0"        # single-launch slab reductions (A/B switch; bit-identical)
 _FUSED_BN = os.environ.get("MAU_FUSED_BN", "1") != "0"                # BatchNorm passes fused with pool / head / upsample (A/B switch; bit-identical)
 _FUSED_UP = os.environ.get("MAU_FUSED_UP", "1") != "0"                # (the upsample member of the above, separately switchable)
+_FIRST_WGRAD = os.environ.get("MAU_FIRST_WGRAD", "1") != "0"          # the first layer's weight gradient on its own kernel (A/B switch)
 _SIDE_STREAMS = {}
 
 
@@ -703,7 +704,8 @@ class ConvBNReLU(torch.autograd.Function):
                 side.wait_stream(torch.cuda.current_stream())           # dy is complete
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 # (workspaces of the side stream's kernels belong to ITS allocator pool: freed here, re-used there)
-                acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin), **f32)
+                acc = torch.empty(max(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin),
+                                      lib.mau_conv3x3_first_wgrad_ws_elems(N, H, W, Cout) if st.first else 0), **f32)
                 emb_ws = torch.empty((N, E), dtype=y.dtype, device=dev) if E else None
             # data parallel (dist.GradSync): the split-K sum is written straight into the parameter's slot of the gradient arena
             # and autograd adopts the returned view as weight.grad -- no copy into the arena later.  Only for the FIRST
@@ -715,11 +717,15 @@ class ConvBNReLU(torch.autograd.Function):
             # accumulating AccumulateGrad would add on the main stream to what the side stream is still writing
             # (and only for a parameter: the gradient of a derived weight -- EmbFold's W_eff -- is read by ITS backward on the main stream)
             deferred = side is not None and overlap >= 2 and weight.is_leaf and weight.grad is None
-            call("mau_conv3x3_wgrad2", x.data_ptr(), _ld(x), st.C0, x1.data_ptr() if x1 is not None else None,
-                 _ld(x1) if x1 is not None else 0, C1, emb.data_ptr() if E else None,
-                 emb_ws.data_ptr() if E else None, E, dy.data_ptr(), ldy, Cout, acc.data_ptr(), code, N, H, W, wstream)
-            call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin),
-                 dw.data_ptr(), Cout, Cin, wstream)
+            if st.first and _FIRST_WGRAD:
+                # conv0_0.conv1: K = pixels, N = 9 taps x 8 channels straight from the forward's NHWC-8 by-product (csrc/conv3x3_first.hip)
+                call("mau_conv3x3_first_wgrad", x.data_ptr(), dy.data_ptr(), ldy, dw.data_ptr(), acc.data_ptr(), Cin, Cout, code, N, H, W, wstream)
+            else:
+                call("mau_conv3x3_wgrad2", x.data_ptr(), _ld(x), st.C0, x1.data_ptr() if x1 is not None else None,
+                     _ld(x1) if x1 is not None else 0, C1, emb.data_ptr() if E else None,
+                     emb_ws.data_ptr() if E else None, E, dy.data_ptr(), ldy, Cout, acc.data_ptr(), code, N, H, W, wstream)
+                call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin),
+                     dw.data_ptr(), Cout, Cin, wstream)
             if deferred:
                 for t in (x, x1, emb, dy, dw):                           # read / written over there after this function has returned
                     if t is not None:

@@ -34,4 +34,19 @@ f_old = lambda: call("mau_conv3x3_fwd", x8.data_ptr(), 8, Cin, None, None, 0, wf
 mb = (B * Cin * S * S * 4 + B * S * S * Cout * 2) / 1e6
 for name, f, bytes_mb in (("first_fwd (+x8 by-product)", f_new, mb + B * S * S * 16 / 1e6), ("first_fwd (no by-product)", f_new_nox8, mb), ("generic: nchw_to_nhwc", f_lay, None), ("generic: conv3x3_fwd 16-channel stage", f_old, None)):
     us = timeit(f)
-    print(f"{name:40s} {us:8.1f} us" + (f"   {bytes_mb / us * 1e-6 * 1e6 / 1e3:6.2f} TB/s of {bytes_mb:.0f} MB" if bytes_mb else ""))
+    print(f"{name:40s} {us:8.1f} us" + (f"   {bytes_mb / us:6.2f} TB/s of {bytes_mb:.0f} MB" if bytes_mb else ""))
+
+# ---- the layer's weight gradient: its own kernel against the generic split-K kernel + unpack ----
+dz = torch.randn(B, S, S, Cout, device="cuda").to(dt)
+dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+ws = torch.empty(lib.mau_conv3x3_first_wgrad_ws_elems(B, S, S, Cout), device="cuda")
+acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, B, S, S, Cout, Cin), device="cuda")
+ns = lib.mau_conv3x3_wgrad_splits(code, B, S, S, Cout, Cin)
+f_fw = lambda: call("mau_conv3x3_first_wgrad", x8.data_ptr(), dz.data_ptr(), Cout, dw.data_ptr(), ws.data_ptr(), Cin, Cout, code, B, S, S, st)
+def f_gw():
+    call("mau_conv3x3_wgrad", x8.data_ptr(), 8, Cin, None, None, 0, dz.data_ptr(), Cout, Cout, acc.data_ptr(), code, B, S, S, st)
+    call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), ns, dw.data_ptr(), Cout, Cin, st)
+mbw = (B * S * S * Cout * 2 + B * S * S * 16) / 1e6
+for name, f in (("first_wgrad (+ slab sum)", f_fw), ("generic: wgrad16 split-K + unpack", f_gw)):
+    us = timeit(f)
+    print(f"{name:40s} {us:8.1f} us   {mbw / us:6.2f} TB/s of {mbw:.0f} MB")

@@ -744,3 +744,36 @@ def test_first_layer_path_matches_generic_path(prec, monkeypatch):
     den = sum(float((b[2][k].double() ** 2).sum()) for k in a[2])
     assert (num / den) ** 0.5 < 0.15, (num / den) ** 0.5                      # (bf16 noise of this tiny network: ReLU-mask flips)
     assert rel_l2(a[2]["model.conv0_0.conv1.weight"], b[2]["model.conv0_0.conv1.weight"]) < 0.15
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 6, 64, 64, 128), (1, 6, 64, 250, 250), (3, 3, 8, 31, 47), (2, 8, 16, 16, 64), (1, 1, 128, 40, 70), (2, 6, 96, 33, 65)])
+def test_first_layer_weight_gradient_exact(dt, N, Cin, Cout, H, W):
+    """mau_conv3x3_first_wgrad: dW of the first convolution from the forward's NHWC-8 by-product and dz, K = pixels on
+    v_mfma_f32_16x16x32 with both operands through transposed LDS reads -- exact on small-integer data against autograd's
+    conv2d weight gradient (src/train.py:252), ragged widths (not a multiple of the 32-pixel tile), narrow and wide layers, and
+    bitwise reproducible (fixed-order sums)."""
+    from mau_amd import functional as F_
+    from mau_amd._lib import call, lib
+    code = F_.dtype_code(dt)
+    g = torch.Generator().manual_seed(N * 1000 + Cin * 100 + Cout + 7)
+    x = torch.randint(-3, 4, (N, Cin, H, W), generator=g).float().cuda()
+    dz = torch.randint(-2, 3, (N, Cout, H, W), generator=g).float().cuda()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dz.double(), padding=1)
+    ldz = F_.pad8(Cout)
+    x8 = torch.zeros((N, H, W, 8), device="cuda", dtype=dt)
+    x8[..., :Cin] = x.permute(0, 2, 3, 1).to(dt)
+    dzl = torch.zeros((N, H, W, ldz), device="cuda", dtype=dt)
+    dzl[..., :Cout] = dz.permute(0, 2, 3, 1).to(dt)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.full((lib.mau_conv3x3_first_wgrad_ws_elems(N, H, W, Cout),), float("nan"), device="cuda")
+    outs = []
+    for _ in range(2):
+        dw = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+        call("mau_conv3x3_first_wgrad", x8.data_ptr(), dzl.data_ptr(), ldz, dw.data_ptr(), ws.data_ptr(), Cin, Cout, code, N, H, W, st)
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert torch.equal(outs[0].double(), ref), float((outs[0].double() - ref).abs().max())
+    assert torch.equal(outs[0], outs[1])
+    with pytest.raises(Exception, match="input channels"):
+        call("mau_conv3x3_first_wgrad", x8.data_ptr(), dzl.data_ptr(), ldz, dw.data_ptr(), ws.data_ptr(), 9, Cout, code, N, H, W, st)
