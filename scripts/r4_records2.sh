@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp
 R=gpurun_out/rec4; mkdir -p $R
-cp profiles/r4/pmc_summary.json gpurun_out/r4_profiles/pmc_summary.json 2>/dev/null
+mkdir -p gpurun_out/r4_profiles && cp profiles/r4/pmc_summary.json gpurun_out/r4_profiles/pmc_summary.json
 bash scripts/profile.sh r4upp --no-graph --repeats 1 --model-type unet++ --batch 16
 python scripts/summarize_profile.py gpurun_out/prof_r4upp gpurun_out/r4_profiles unet++_bf16_b16_s256_c6_train > $R/profiles_summ_unetpp.txt 2>&1; echo "summ upp rc=$?"
 bash scripts/profile.sh r4inf --no-graph --repeats 1 --infer --size 512 --batch 8
