@@ -288,7 +288,13 @@ def _agree_on_port(attempt: int, timeout: float = 120.0) -> int:
     every rank it started) and the attempt; the others wait for the file.  The launcher's own store is not used for the
     workers: it has no per-attempt key space, so the addresses a failed attempt left there would poison the next one."""
     import tempfile
-    path = os.path.join(tempfile.gettempdir(), f"mau_bench_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{attempt}.port")
+    ppid = os.getppid()
+    try:                      # the launcher's start time (clock ticks since boot) tells two launchers apart that got the same pid
+        with open(f"/proc/{ppid}/stat") as f:
+            born = f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        born = "0"
+    path = os.path.join(tempfile.gettempdir(), f"mau_bench_{ppid}_{born}_{os.environ.get('MASTER_PORT', '0')}_{attempt}.port")
     if int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))) == 0:
         port = _free_port()
         with open(path + ".tmp", "w") as f:
