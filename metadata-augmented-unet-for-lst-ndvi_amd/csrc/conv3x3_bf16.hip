@@ -289,6 +289,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MAU_CONV_SETPRIO      // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for the second-dispatched half
+  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int wm = wave % WM, wn = wave / WM;
   const int i32 = perm32(lane & 31), h = lane >> 5;   // tile row (pixel / channel) this lane's operands come from
 
