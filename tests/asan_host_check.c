@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
   SYM(mau_l1_gradient_blocks) SYM(mau_lstm_bwd_ws_elems) SYM(mau_ssim_ws_elems) SYM(mau_lstm_max_hidden)
   SYM(mau_conv3x3_fwd) SYM(mau_conv3x3_fwd2) SYM(mau_conv3x3_wgrad2) SYM(mau_bn_relu_apply) SYM(mau_maxpool2x2_fwd)
   SYM(mau_linear_fwd) SYM(mau_resize_bilinear_fwd) SYM(mau_head_fwd) SYM(mau_lstm_fwd) SYM(mau_ssim_loss) SYM(mau_nchw_to_nhwc) SYM(mau_copy_channels) SYM(mau_emb_fold_fwd)
+  SYM(mau_conv3x3_first_max_channels) SYM(mau_conv3x3_first_rows) SYM(mau_conv3x3_first_fwd) SYM(mau_conv3x3_first_wgrad_ws_elems) SYM(mau_conv3x3_first_wgrad)
   if (p_mau_abi_version() != 3) return 5;
   size_t acc = 0;
   for (int dt = MAU_F32; dt <= MAU_F16; ++dt) {
@@ -35,6 +36,9 @@ int main(int argc, char** argv) {
   acc += p_mau_bcast_bwd_ws_elems(16, 65536, 128) + (size_t)p_mau_head_bwd_rows(32, 65536) + (size_t)p_mau_head_bwd_rowlen(64, 2);
   acc += (size_t)p_mau_mse_blocks(1 << 24) + (size_t)p_mau_l1_gradient_blocks(1 << 24) + p_mau_lstm_bwd_ws_elems(32, 828, 96);
   acc += p_mau_ssim_ws_elems(32, 2, 250, 250) + (size_t)p_mau_lstm_max_hidden();
+  if (p_mau_conv3x3_first_max_channels() != 8) return 7;
+  acc += (size_t)p_mau_conv3x3_first_rows(32, 256, 256) + (size_t)p_mau_conv3x3_first_rows(1, 31, 47) + p_mau_conv3x3_first_wgrad_ws_elems(32, 256, 256, 64)
+         + p_mau_conv3x3_first_wgrad_ws_elems(3, 31, 47, 8) + (size_t)p_mau_conv3x3_first_rows(0, 4, 4);
   float dummy[64];
   REFUSED(p_mau_conv3x3_fwd(dummy, 12, 12, NULL, NULL, 0, dummy, NULL, NULL, NULL, dummy, 8, 8, NULL, MAU_BF16, 1, 4, 4, NULL));   /* ld % 8 */
   REFUSED(p_mau_conv3x3_fwd(NULL, 8, 8, NULL, NULL, 0, dummy, NULL, NULL, NULL, dummy, 8, 8, NULL, MAU_BF16, 1, 4, 4, NULL));      /* null x */
@@ -50,6 +54,13 @@ int main(int argc, char** argv) {
   REFUSED(p_mau_nchw_to_nhwc(dummy, dummy, MAU_BF16, 1, 9, 2, 2, 8, NULL));                                                     /* ld < C */
   REFUSED(p_mau_emb_fold_fwd((const float*)dummy, (const float*)dummy, (float*)dummy, 8, 16, 128, 32, 16, NULL));                             /* Ep < N */
   REFUSED(p_mau_copy_channels(dummy, 8, dummy, 8, 4, 0, MAU_BF16, 4, 8, NULL));                                                 /* choff + C > ld */
+  REFUSED(p_mau_conv3x3_first_fwd(dummy, 9, dummy, NULL, NULL, NULL, dummy, 64, 64, NULL, NULL, MAU_BF16, 1, 4, 4, NULL));        /* > 8 input channels */
+  REFUSED(p_mau_conv3x3_first_fwd(dummy, 6, dummy, NULL, NULL, NULL, dummy, 64, 64, NULL, NULL, MAU_F32, 1, 4, 4, NULL));         /* fp32 = parity mode */
+  REFUSED(p_mau_conv3x3_first_fwd(dummy, 6, dummy, NULL, dummy, NULL, dummy, 64, 64, NULL, NULL, MAU_BF16, 1, 4, 4, NULL));       /* scale without shift */
+  REFUSED(p_mau_conv3x3_first_fwd(dummy, 6, dummy, NULL, NULL, NULL, dummy, 12, 12, NULL, NULL, MAU_BF16, 1, 4, 4, NULL));        /* ldy % 8 */
+  REFUSED(p_mau_conv3x3_first_wgrad(dummy, dummy, 64, dummy, dummy, 9, 64, MAU_BF16, 1, 4, 4, NULL));                            /* > 8 input channels */
+  REFUSED(p_mau_conv3x3_first_wgrad(dummy, dummy, 60, dummy, dummy, 6, 64, MAU_BF16, 1, 4, 4, NULL));                            /* lddz % 8, < Cout */
+  REFUSED(p_mau_conv3x3_first_wgrad(dummy, dummy, 64, dummy, NULL, 6, 64, MAU_F16, 1, 4, 4, NULL));                              /* no workspace */
   printf("asan host check OK (%zu)\n", acc);
   return 0;
 }
