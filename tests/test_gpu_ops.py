@@ -541,15 +541,16 @@ def test_device_loader_prefetches_compact_batches(mau, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m16", ["1", "0"])
-def test_conv3x3_big_tile_variants_exact(m16):
+@pytest.mark.parametrize("m16,l0", [("1", "1"), ("0", "1"), ("1", "0")])
+def test_conv3x3_big_tile_variants_exact(m16, l0):
     """The production layers run the big-tile variants (<128,4,8>, <64,4,8>: picked only when the work items fill the chip),
     which the small cases above never select: exact-integer forward (+ BatchNorm partial sums), data gradient and inference
     epilogue at such sizes, one and two tensor sources, ragged images, bf16 and fp16 -- in a child process, because the
-    loop is chosen once per process: MAU_CONV_M16=1 the v_mfma 16x16x32 stage-pair loop, 0 the 32x32x16 loop."""
+    loop is chosen once per process: MAU_CONV_M16=1 the v_mfma 16x16x32 stage-pair loop, 0 the 32x32x16 loop;
+    MAU_CONV_L0=1 (default) the two-workgroups-per-CU <64,4,4> variant on the 64-channel layers, 0 the <64,4,8> one."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MAU_CONV_M16=m16)
+    env = dict(os.environ, MAU_CONV_M16=m16, MAU_CONV_L0=l0)
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "conv_big_tile_check.py")], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "ALL OK" in p.stdout, (p.stdout[-3000:], p.stderr[-2000:])
 
