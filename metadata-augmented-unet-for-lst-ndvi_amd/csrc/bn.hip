@@ -14,6 +14,37 @@
 
 namespace mau {
 
+// ---- the fixed-order two-accumulator sum of the reductions below, with every load of a group in flight at once ----
+//     s0 += v[first], v[first + 8], ...;   s1 += v[first + 4], v[first + 12], ...      (indices < end, ascending)
+// is the arithmetic of the plain loop "for (k = first; k + 4 < end; k += 8) { s0 += v[k]; s1 += v[k + 4]; } if (k < end) s0 += v[k];"
+// -- same operands, same order, same bits.  As that loop the level was a chain of dependent round trips (each iteration's
+// loads were issued after the previous iteration's additions: 16 trips of ~0.65 us through L2 for 128 chunks; the finalize
+// launches of the 256^2 / 128^2 layers took 14 us against 5.5 us for the layers with <= 16 chunks).  Here G iterations' loads
+// are issued back to back (clamped index, value dropped by the predicated addition) and the additions follow in order.
+template <int G_, typename Load>
+__device__ __forceinline__ void ordered_pair_sum(int first, int end, Load load, double& s0, double& s1) {
+#ifdef MAU_REDUCE_SERIAL            // A/B (scripts/build_variants.sh): one iteration's loads at a time, as the plain loop
+  constexpr int G = 1;
+#else
+  constexpr int G = G_;
+#endif
+  for (int base = first; base < end; base += 8 * G) {
+    double a[G], b[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int k = base + 8 * i;
+      a[i] = load(k < end ? k : first);
+      b[i] = load(k + 4 < end ? k + 4 : first);
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int k = base + 8 * i;
+      if (k < end) s0 += a[i];
+      if (k + 4 < end) s1 += b[i];
+    }
+  }
+}
+
 // ---- column sums of a row-major slab [rows][ldrow] -> out[M], accumulated in fp64 ----
 // Two levels, both deterministic: level 1 cuts the rows into gridDim.y chunks and writes fp64
 // partials [chunk][M]; level 2 (same kernel, one chunk) adds the partials in fixed order.
@@ -28,15 +59,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const InT* __restrict_
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double s0 = 0.0, s1 = 0.0;
   if (col < M) {
-    int r = r0 + rl;
-    // (unrolled x4: 8 loads in flight per thread instead of 2 -- the level is a latency chain of a few dozen rows per thread; the
-    //  additions keep their order)
-#pragma unroll 4
-    for (; r + 4 < r1; r += 8) {
-      s0 += (double)slab[(size_t)r * ldrow + col];
-      s1 += (double)slab[(size_t)(r + 4) * ldrow + col];
-    }
-    if (r < r1) s0 += (double)slab[(size_t)r * ldrow + col];
+    if (r0 + rl < r1) ordered_pair_sum<16>(r0 + rl, r1, [&](int r) { return (double)slab[(size_t)r * ldrow + col]; }, s0, s1);
   }
   part[rl][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
@@ -110,15 +133,7 @@ __global__ __launch_bounds__(256) void reduce_rows_fused_kernel(const float* __r
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double s0 = 0.0, s1 = 0.0;
   if (j < M) {
-    int r = r0 + rl;
-    // (unrolled x4: 8 loads in flight per thread instead of 2 -- the level is a latency chain of a few dozen rows per thread; the
-    //  additions keep their order)
-#pragma unroll 4
-    for (; r + 4 < r1; r += 8) {
-      s0 += (double)slab[(size_t)r * ldrow + col];
-      s1 += (double)slab[(size_t)(r + 4) * ldrow + col];
-    }
-    if (r < r1) s0 += (double)slab[(size_t)r * ldrow + col];
+    if (r0 + rl < r1) ordered_pair_sum<16>(r0 + rl, r1, [&](int r) { return (double)slab[(size_t)r * ldrow + col]; }, s0, s1);
   }
   ps[rl][cl] = s0 + s1;
   __syncthreads();
@@ -127,12 +142,7 @@ __global__ __launch_bounds__(256) void reduce_rows_fused_kernel(const float* __r
   // level 2: the chunks' partials in a fixed order (the order of reduce_rows_kernel<double, OutT> on one chunk)
   s0 = s1 = 0.0;
   if (j < M) {
-    int k = rl;
-    for (; k + 4 < chunks; k += 8) {
-      s0 += part[(size_t)k * M + j];
-      s1 += part[(size_t)(k + 4) * M + j];
-    }
-    if (k < chunks) s0 += part[(size_t)k * M + j];
+    if (rl < chunks) ordered_pair_sum<16>(rl, chunks, [&](int k) { return part[(size_t)k * M + j]; }, s0, s1);
   }
   ps[rl][cl] = s0 + s1;
   __syncthreads();
@@ -192,18 +202,9 @@ __global__ __launch_bounds__(256) void bn_finalize_from_partials_kernel(const do
   const int c = blockIdx.x * 64 + cl;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-  if (c < C) {
-    int k = kl;
-    for (; k + 4 < chunks; k += 8) {
-      s0 += part[(size_t)k * 2 * ldp + c];
-      q0 += part[(size_t)k * 2 * ldp + ldp + c];
-      s1 += part[(size_t)(k + 4) * 2 * ldp + c];
-      q1 += part[(size_t)(k + 4) * 2 * ldp + ldp + c];
-    }
-    if (k < chunks) {
-      s0 += part[(size_t)k * 2 * ldp + c];
-      q0 += part[(size_t)k * 2 * ldp + ldp + c];
-    }
+  if (c < C && kl < chunks) {
+    ordered_pair_sum<16>(kl, chunks, [&](int k) { return part[(size_t)k * 2 * ldp + c]; }, s0, s1);
+    ordered_pair_sum<16>(kl, chunks, [&](int k) { return part[(size_t)k * 2 * ldp + ldp + c]; }, q0, q1);
   }
   ps[kl][cl] = s0 + s1;
   pq[kl][cl] = q0 + q1;
@@ -244,19 +245,9 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_fused_kernel(const floa
   const int per = (rows + chunks - 1) / chunks;
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
-  {
-    int r = r0 + kl;
-#pragma unroll 4
-    for (; r + 4 < r1; r += 8) {
-      s0 += (double)slab[(size_t)r * ld + c];
-      q0 += (double)slab[(size_t)r * ld + cpad + c];
-      s1 += (double)slab[(size_t)(r + 4) * ld + c];
-      q1 += (double)slab[(size_t)(r + 4) * ld + cpad + c];
-    }
-    if (r < r1) {
-      s0 += (double)slab[(size_t)r * ld + c];
-      q0 += (double)slab[(size_t)r * ld + cpad + c];
-    }
+  if (r0 + kl < r1) {
+    ordered_pair_sum<16>(r0 + kl, r1, [&](int r) { return (double)slab[(size_t)r * ld + c]; }, s0, s1);
+    ordered_pair_sum<16>(r0 + kl, r1, [&](int r) { return (double)slab[(size_t)r * ld + cpad + c]; }, q0, q1);
   }
   ps[kl][cl] = s0 + s1;
   pq[kl][cl] = q0 + q1;
@@ -268,18 +259,9 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_fused_kernel(const floa
   if (!last_block_of(tickets + blockIdx.x, (unsigned)chunks)) return;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   s0 = q0 = s1 = q1 = 0.0;
-  if (c < C) {
-    int k = kl;
-    for (; k + 4 < chunks; k += 8) {
-      s0 += part[(size_t)k * ld + c];
-      q0 += part[(size_t)k * ld + cpad + c];
-      s1 += part[(size_t)(k + 4) * ld + c];
-      q1 += part[(size_t)(k + 4) * ld + cpad + c];
-    }
-    if (k < chunks) {
-      s0 += part[(size_t)k * ld + c];
-      q0 += part[(size_t)k * ld + cpad + c];
-    }
+  if (c < C && kl < chunks) {
+    ordered_pair_sum<16>(kl, chunks, [&](int k) { return part[(size_t)k * ld + c]; }, s0, s1);
+    ordered_pair_sum<16>(kl, chunks, [&](int k) { return part[(size_t)k * ld + cpad + c]; }, q0, q1);
   }
   ps[kl][cl] = s0 + s1;
   pq[kl][cl] = q0 + q1;

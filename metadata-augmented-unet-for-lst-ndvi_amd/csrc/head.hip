@@ -189,24 +189,28 @@ __global__ void meta_mlp_fwd2_kernel(const float* __restrict__ hidden, const flo
 }
 // one block; N is a batch (<= a few hundred), Hd = 32, D <= 256: everything fits one workgroup's loops
 // Backward in two grid-wide phases (a single 256-thread block looping over everything took 88 us of pure latency):
-// phase 1: dW2, db2 and dhidden (through the ReLU);  phase 2: dW0, db0 from dhidden.  Sums over the batch in index order.
+// phase 1: dW2, db2 and dhidden (through the ReLU);  phase 2: dW0, db0 from dhidden.  Sums over the batch in index order
+// (loops unrolled x8: eight iterations' loads in flight, the fma chain keeps its order -- the kernels are chains of L2 round trips).
 __global__ void meta_mlp_bwd1_kernel(const float* __restrict__ w2, const float* __restrict__ hidden, const float* __restrict__ demb,
                                      float* __restrict__ dw2, float* __restrict__ db2, float* __restrict__ dhid_ws, int N, int Hd, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < D * Hd) {                            // dW2[d][j] = sum_n demb[n][d] * hidden[n][j]
     const int d = i / Hd, j = i % Hd;
     float s = 0.f;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) s = fmaf(demb[n * D + d], hidden[n * Hd + j], s);
     dw2[i] = s;
   }
   if (i < D) {
     float s = 0.f;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) s += demb[n * D + i];
     db2[i] = s;
   }
   if (i < N * Hd) {                            // dhidden (through ReLU)
     const int n = i / Hd, j = i % Hd;
     float s = 0.f;
+#pragma unroll 8
     for (int d = 0; d < D; ++d) s = fmaf(demb[n * D + d], w2[d * Hd + j], s);
     dhid_ws[i] = hidden[i] > 0.f ? s : 0.f;
   }
@@ -217,11 +221,13 @@ __global__ void meta_mlp_bwd2_kernel(const float* __restrict__ md, const float* 
   if (i < Hd * F) {
     const int j = i / F, f = i % F;
     float s = 0.f;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) s = fmaf(dhid_ws[n * Hd + j], md[n * F + f], s);
     dw0[i] = s;
   }
   if (i < Hd) {
     float s = 0.f;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) s += dhid_ws[n * Hd + i];
     db0[i] = s;
   }
