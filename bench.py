@@ -13,7 +13,8 @@ rank runs under a SUPERVISOR that never touches the GPU: `python bench.py --gpus
 workers itself; under torch.distributed.run each launched rank is the supervisor of its own worker.
 Attempt 1 runs the workers with MAU_DP_GRAPH=1; a worker that exits non-zero or stops reporting
 progress is killed (with its process group) and a FRESH set of workers runs the eager step
-(MAU_DP_GRAPH=0) on a fresh rendezvous.  Nothing is ever exec'ed or restarted in place.
+(MAU_DP_GRAPH=0) on a fresh rendezvous; should that fail too, a last set runs the eager step with every
+collective through ProcessGroupNCCL (MAU_RCCL_DIRECT=0).  Nothing is ever exec'ed or restarted in place.
 The timed region (exactly K steps between barrier + synchronize) is repeated R times back to back
 (R chosen so the GPU phase lasts >= ~10 s) and the MEDIAN region is reported; the spread is in the line.
 Workload (BASELINE.json configs[1] / configs[3]): U-Net, base_filters 64, 6x256x256 tiles + 4-dim
@@ -246,12 +247,19 @@ def supervise_workers(cmds_envs, limits=None, poll=0.2, log=sys.stderr):
 
 def run_supervised(make_attempt, log=sys.stderr):
     """Attempt 1: captured data-parallel step (MAU_DP_GRAPH=1) unless the environment pins the mode; attempt 2 (only after a
-    failed attempt 1): eager step, fresh workers, fresh rendezvous.  ``make_attempt(k, dp_graph)`` -> list of (cmd, env).
-    Prints the surviving attempt's JSON line; exit code 0 iff one attempt succeeded."""
+    failed attempt 1): eager step, fresh workers, fresh rendezvous; attempt 3 (only after a failed attempt 2, and unless the
+    environment pins MAU_RCCL_DIRECT): the eager step with every collective through ProcessGroupNCCL (MAU_RCCL_DIRECT=0, round
+    3's path: slower, but the one torch itself exercises everywhere).  ``make_attempt(k, dp_graph)`` -> list of (cmd, env).
+    Prints the surviving attempt's JSON line -- its ``config.launch`` / ``config.collectives`` say which attempt that was;
+    exit code 0 iff one attempt succeeded."""
     pinned = os.environ.get("MAU_DP_GRAPH")
-    plan = [pinned == "1"] if pinned in ("0", "1") else [True, False]
-    for k, dp_graph in enumerate(plan):
-        ok, out = supervise_workers(make_attempt(k, dp_graph), log=log)
+    plan = [(pinned == "1", {})] if pinned in ("0", "1") else [(True, {}), (False, {})]
+    if os.environ.get("MAU_RCCL_DIRECT") is None and not plan[-1][0]:
+        plan.append((False, {"MAU_RCCL_DIRECT": "0"}))
+    what = {True: "captured data-parallel step", False: "eager data-parallel step"}
+    for k, (dp_graph, extra) in enumerate(plan):
+        attempt = [(cmd, dict(env, **extra)) for cmd, env in make_attempt(k, dp_graph)]
+        ok, out = supervise_workers(attempt, log=log)
         lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
         for ln in out.splitlines():
             if ln not in lines:
@@ -261,7 +269,9 @@ def run_supervised(make_attempt, log=sys.stderr):
                 print(lines[-1], flush=True)
             return 0
         if k + 1 < len(plan):
-            print("bench.py supervisor: falling back to the eager data-parallel step with fresh workers", file=log, flush=True)
+            nxt = plan[k + 1]
+            print(f"bench.py supervisor: falling back to the {what[nxt[0]]}" + (" over ProcessGroupNCCL" if nxt[1] else "") + " with fresh workers",
+                  file=log, flush=True)
     return 1
 
 

@@ -28,6 +28,9 @@ FAKE = textwrap.dedent(r'''
     print("some library banner on stdout")                       # RCCL prints one: the supervisor must not take it for the line
     if graph and mode == "exit" and bad:
         sys.exit(1)
+    direct = os.environ.get("MAU_RCCL_DIRECT", "1") != "0"
+    if direct and os.environ.get("MAU_FAKE_DIRECT_FAILURE") == "exit" and bad:
+        sys.exit(1)                                              # the directly-called RCCL path fails, captured or eager
     if graph and mode == "hang":
         if bad:
             time.sleep(600)                                      # the rank that hangs in its capture ...
@@ -36,7 +39,8 @@ FAKE = textwrap.dedent(r'''
     print(tag, "captured", file=sys.stderr, flush=True)
     print(tag, "timed", file=sys.stderr, flush=True)
     if rank == 0:
-        print(json.dumps({"metric": "fake", "value": 1.0, "launch": "graph" if graph else "eager", "port": os.environ["MASTER_PORT"]}), flush=True)
+        print(json.dumps({"metric": "fake", "value": 1.0, "launch": "graph" if graph else "eager", "port": os.environ["MASTER_PORT"],
+                          "collectives": "direct" if direct else "pg"}), flush=True)
     print(tag, "done", file=sys.stderr, flush=True)
     if os.environ.get("MAU_FAKE_EXIT_AFTER_DONE") == "1":
         sys.exit(3)                                              # e.g. a crash in destroy_process_group: the result is already out
@@ -61,6 +65,7 @@ def _attempts(tmp_path, world, extra_env):
 
 def _run(tmp_path, capsys, monkeypatch, world=2, **extra_env):
     monkeypatch.delenv("MAU_DP_GRAPH", raising=False)
+    monkeypatch.delenv("MAU_RCCL_DIRECT", raising=False)
     make_attempt, made = _attempts(tmp_path, world, extra_env)
     log = io.StringIO()
     rc = bench.run_supervised(make_attempt, log=log)
@@ -92,13 +97,27 @@ def test_falls_back_when_a_rank_hangs(tmp_path, capsys, monkeypatch):
     assert "made no progress" in log
 
 
+def test_third_attempt_goes_through_process_group_nccl(tmp_path, capsys, monkeypatch):
+    # the directly-called RCCL path fails in both launch modes: the last attempt runs eagerly with MAU_RCCL_DIRECT=0
+    rc, made, lines, log = _run(tmp_path, capsys, monkeypatch, MAU_FAKE_DIRECT_FAILURE="exit", MAU_FAKE_BAD_RANK="1")
+    assert rc == 0 and made == [(0, True), (1, False), (2, False)]
+    rec = json.loads(lines[0])
+    assert len(lines) == 1 and rec["launch"] == "eager" and rec["collectives"] == "pg" and rec["port"] == "29002"
+    assert "over ProcessGroupNCCL" in log
+    # MAU_RCCL_DIRECT pinned by the caller: no third attempt
+    monkeypatch.setenv("MAU_RCCL_DIRECT", "1")
+    make_attempt, made = _attempts(tmp_path, 2, {"MAU_FAKE_DIRECT_FAILURE": "exit"})
+    assert bench.run_supervised(make_attempt, log=io.StringIO()) == 1 and made == [(0, True), (1, False)]
+
+
 def test_exit_code_after_done_does_not_discard_the_result(tmp_path, capsys, monkeypatch):
     rc, made, lines, _ = _run(tmp_path, capsys, monkeypatch, MAU_FAKE_EXIT_AFTER_DONE="1")
     assert rc == 0 and made == [(0, True)] and json.loads(lines[0])["launch"] == "graph"
 
 
 def test_pinned_mode_and_total_failure(tmp_path, capsys, monkeypatch):
-    # MAU_DP_GRAPH=0 in the environment: one eager attempt only
+    # MAU_DP_GRAPH=0 in the environment: eager attempts only
+    monkeypatch.delenv("MAU_RCCL_DIRECT", raising=False)
     monkeypatch.setenv("MAU_DP_GRAPH", "0")
     make_attempt, made = _attempts(tmp_path, 2, {})
     assert bench.run_supervised(make_attempt, log=io.StringIO()) == 0 and made == [(0, False)]
