@@ -14,35 +14,43 @@
 
 namespace mau {
 
-// ---- the fixed-order two-accumulator sum of the reductions below, with every load of a group in flight at once ----
+// ---- the fixed-order two-accumulator sum of the reductions below, with a group's loads in flight at once ----
 //     s0 += v[first], v[first + 8], ...;   s1 += v[first + 4], v[first + 12], ...      (indices < end, ascending)
 // is the arithmetic of the plain loop "for (k = first; k + 4 < end; k += 8) { s0 += v[k]; s1 += v[k + 4]; } if (k < end) s0 += v[k];"
 // -- same operands, same order, same bits.  As that loop the level was a chain of dependent round trips (each iteration's
 // loads were issued after the previous iteration's additions: 16 trips of ~0.65 us through L2 for 128 chunks; the finalize
-// launches of the 256^2 / 128^2 layers took 14 us against 5.5 us for the layers with <= 16 chunks).  Here G iterations' loads
-// are issued back to back (clamped index, value dropped by the predicated addition) and the additions follow in order.
-template <int G_, typename Load>
-__device__ __forceinline__ void ordered_pair_sum(int first, int end, Load load, double& s0, double& s1) {
-#ifdef MAU_REDUCE_SERIAL            // A/B (scripts/build_variants.sh): one iteration's loads at a time, as the plain loop
-  constexpr int G = 1;
-#else
-  constexpr int G = G_;
-#endif
-  for (int base = first; base < end; base += 8 * G) {
+// launches of the 256^2 / 128^2 layers took 14 us against 5.5 us for the layers with <= 16 chunks).  Here whole groups of 16,
+// then of 4 iterations issue their loads back to back and add in order; what is left (< 4 iterations) runs as the plain loop,
+// so the short reductions of the deep layers execute exactly what they did before.  (A single 16-wide group with clamped
+// indices and predicated additions for every length cost the short ones +3.5 us of instruction issue: 4 waves, one per SIMD.)
+template <int G, typename Load>
+__device__ __forceinline__ void ordered_group(int& k, int end, Load load, double& s0, double& s1) {
+  for (; k + 8 * (G - 1) + 4 < end; k += 8 * G) {          // every index of the group is valid
     double a[G], b[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) {
-      const int k = base + 8 * i;
-      a[i] = load(k < end ? k : first);
-      b[i] = load(k + 4 < end ? k + 4 : first);
+      a[i] = load(k + 8 * i);
+      b[i] = load(k + 8 * i + 4);
     }
 #pragma unroll
     for (int i = 0; i < G; ++i) {
-      const int k = base + 8 * i;
-      if (k < end) s0 += a[i];
-      if (k + 4 < end) s1 += b[i];
+      s0 += a[i];
+      s1 += b[i];
     }
   }
+}
+template <typename Load>
+__device__ __forceinline__ void ordered_pair_sum(int first, int end, Load load, double& s0, double& s1) {
+  int k = first;
+#ifndef MAU_REDUCE_SERIAL           // A/B (scripts/build_variants.sh): the plain loop alone
+  ordered_group<16>(k, end, load, s0, s1);
+  ordered_group<4>(k, end, load, s0, s1);
+#endif
+  for (; k + 4 < end; k += 8) {
+    s0 += load(k);
+    s1 += load(k + 4);
+  }
+  if (k < end) s0 += load(k);
 }
 
 // ---- column sums of a row-major slab [rows][ldrow] -> out[M], accumulated in fp64 ----
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const InT* __restrict_
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double s0 = 0.0, s1 = 0.0;
   if (col < M) {
-    if (r0 + rl < r1) ordered_pair_sum<16>(r0 + rl, r1, [&](int r) { return (double)slab[(size_t)r * ldrow + col]; }, s0, s1);
+    if (r0 + rl < r1) ordered_pair_sum(r0 + rl, r1, [&](int r) { return (double)slab[(size_t)r * ldrow + col]; }, s0, s1);
   }
   part[rl][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(256) void reduce_rows_fused_kernel(const float* __r
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double s0 = 0.0, s1 = 0.0;
   if (j < M) {
-    if (r0 + rl < r1) ordered_pair_sum<16>(r0 + rl, r1, [&](int r) { return (double)slab[(size_t)r * ldrow + col]; }, s0, s1);
+    if (r0 + rl < r1) ordered_pair_sum(r0 + rl, r1, [&](int r) { return (double)slab[(size_t)r * ldrow + col]; }, s0, s1);
   }
   ps[rl][cl] = s0 + s1;
   __syncthreads();
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void reduce_rows_fused_kernel(const float* __r
   // level 2: the chunks' partials in a fixed order (the order of reduce_rows_kernel<double, OutT> on one chunk)
   s0 = s1 = 0.0;
   if (j < M) {
-    if (rl < chunks) ordered_pair_sum<16>(rl, chunks, [&](int k) { return part[(size_t)k * M + j]; }, s0, s1);
+    if (rl < chunks) ordered_pair_sum(rl, chunks, [&](int k) { return part[(size_t)k * M + j]; }, s0, s1);
   }
   ps[rl][cl] = s0 + s1;
   __syncthreads();
@@ -203,8 +211,8 @@ __global__ __launch_bounds__(256) void bn_finalize_from_partials_kernel(const do
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
   if (c < C && kl < chunks) {
-    ordered_pair_sum<16>(kl, chunks, [&](int k) { return part[(size_t)k * 2 * ldp + c]; }, s0, s1);
-    ordered_pair_sum<16>(kl, chunks, [&](int k) { return part[(size_t)k * 2 * ldp + ldp + c]; }, q0, q1);
+    ordered_pair_sum(kl, chunks, [&](int k) { return part[(size_t)k * 2 * ldp + c]; }, s0, s1);
+    ordered_pair_sum(kl, chunks, [&](int k) { return part[(size_t)k * 2 * ldp + ldp + c]; }, q0, q1);
   }
   ps[kl][cl] = s0 + s1;
   pq[kl][cl] = q0 + q1;
@@ -246,8 +254,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_fused_kernel(const floa
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double s0 = 0.0, q0 = 0.0, s1 = 0.0, q1 = 0.0;
   if (r0 + kl < r1) {
-    ordered_pair_sum<16>(r0 + kl, r1, [&](int r) { return (double)slab[(size_t)r * ld + c]; }, s0, s1);
-    ordered_pair_sum<16>(r0 + kl, r1, [&](int r) { return (double)slab[(size_t)r * ld + cpad + c]; }, q0, q1);
+    ordered_pair_sum(r0 + kl, r1, [&](int r) { return (double)slab[(size_t)r * ld + c]; }, s0, s1);
+    ordered_pair_sum(r0 + kl, r1, [&](int r) { return (double)slab[(size_t)r * ld + cpad + c]; }, q0, q1);
   }
   ps[kl][cl] = s0 + s1;
   pq[kl][cl] = q0 + q1;
@@ -260,8 +268,8 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_fused_kernel(const floa
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   s0 = q0 = s1 = q1 = 0.0;
   if (c < C && kl < chunks) {
-    ordered_pair_sum<16>(kl, chunks, [&](int k) { return part[(size_t)k * ld + c]; }, s0, s1);
-    ordered_pair_sum<16>(kl, chunks, [&](int k) { return part[(size_t)k * ld + cpad + c]; }, q0, q1);
+    ordered_pair_sum(kl, chunks, [&](int k) { return part[(size_t)k * ld + c]; }, s0, s1);
+    ordered_pair_sum(kl, chunks, [&](int k) { return part[(size_t)k * ld + cpad + c]; }, q0, q1);
   }
   ps[kl][cl] = s0 + s1;
   pq[kl][cl] = q0 + q1;
