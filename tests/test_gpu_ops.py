@@ -778,3 +778,82 @@ def test_first_layer_weight_gradient_exact(dt, N, Cin, Cout, H, W):
     assert torch.equal(outs[0], outs[1])
     with pytest.raises(Exception, match="input channels"):
         call("mau_conv3x3_first_wgrad", x8.data_ptr(), dzl.data_ptr(), ldz, dw.data_ptr(), ws.data_ptr(), 9, Cout, code, N, H, W, st)
+
+
+_REDUCE_ROWS = [1, 2, 3, 4, 5, 8, 9, 31, 33, 63, 64, 65, 127, 129, 255, 1000, 4095, 4096, 4097, 16384, 20001]
+
+
+def test_reduce_rows_every_length_exact_and_order_fixed(mau):
+    """The slab reductions behind every BatchNorm (bn.hip ordered_pair_sum: groups of 16 and 4 iterations with their loads in
+    flight, then the plain tail) at every length class -- one chunk ... 128 chunks of 157 rows: (a) integer-valued slabs, whose
+    sums are exact in any order: a dropped or doubled row shows as an inequality; (b) random slabs: the single-launch (ticket)
+    form is bit-identical to the two-launch form, and both agree with an fp64 sum to rounding."""
+    from mau_amd import functional as F_
+    from mau_amd._lib import call, lib
+    d = torch.device("cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    tk = F_._tickets(d)
+    g = torch.Generator().manual_seed(5)
+    M, ld = 130, 136
+    for rows in _REDUCE_ROWS:
+        ws = torch.empty(lib.mau_reduce_rows_ws_elems(rows, M), dtype=torch.float64, device=d)
+        for kind in ("int", "rand"):
+            slab = (torch.randint(-8, 9, (rows, ld), generator=g).float() if kind == "int" else torch.randn(rows, ld, generator=g) * 100).cuda()
+            ref = slab[:, :M].double().sum(0)
+            outs = []
+            for tickets in (tk.data_ptr(), None):
+                sums = torch.full((M,), float("nan"), dtype=torch.float64, device=d)
+                call("mau_reduce_rows_f64", slab.data_ptr(), rows, M, ld, sums.data_ptr(), ws.data_ptr(), tickets, st)
+                outs.append(sums)
+            s32 = torch.full((M,), float("nan"), device=d)
+            s64 = torch.full((M + 1,), float("nan"), dtype=torch.float64, device=d)
+            call("mau_reduce_rows_f64_f32", slab.data_ptr(), rows, M, ld, s64.data_ptr(), s32.data_ptr(), ws.data_ptr(), tk.data_ptr(), 7.0, st)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[1]), (rows, kind)
+            assert torch.equal(s64[:M], outs[0]) and float(s64[M]) == 7.0 and torch.equal(s32, outs[0].float()), (rows, kind)
+            if kind == "int":
+                assert torch.equal(outs[0], ref), (rows, (outs[0] - ref).abs().max())
+            else:
+                assert float((outs[0] - ref).abs().max()) <= 1e-12 * float(ref.abs().max() + slab.abs().double().sum(0).max()), rows
+    assert int(tk.abs().sum()) == 0                       # every launch left the tickets zeroed
+
+
+def test_bn_stats_finalize_every_length_matches_two_launch_form(mau):
+    """mau_bn_stats_finalize_train, one launch (tickets) against two launches: identical bits at every length class; the
+    moments against fp64 (integer-valued slab: exact sums)."""
+    from mau_amd import functional as F_
+    from mau_amd._lib import call, lib
+    d = torch.device("cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    tk = F_._tickets(d)
+    g = torch.Generator().manual_seed(6)
+    C, cpad = 70, 128
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = torch.randn(C, generator=g).cuda()
+    for rows in _REDUCE_ROWS:
+        slab = torch.zeros(rows, 2 * cpad)
+        slab[:, :C] = torch.randint(-6, 7, (rows, C), generator=g).float()
+        slab[:, cpad:cpad + C] = torch.randint(40, 90, (rows, C), generator=g).float()
+        slab = slab.cuda()
+        count = float(rows)
+        res = []
+        for tickets in (tk.data_ptr(), None):
+            rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
+            nbt = torch.zeros((), dtype=torch.int64, device=d)
+            outs = [torch.full((C,), float("nan"), device=d) for _ in range(4)]
+            ws = torch.empty(lib.mau_bn_stats_ws_elems(rows, C), dtype=torch.float64, device=d)
+            call("mau_bn_stats_finalize_train", slab.data_ptr(), rows, count, gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                 nbt.data_ptr(), 0.1, 1e-5, *(o.data_ptr() for o in outs), ws.data_ptr(), tickets, C, st)
+            torch.cuda.synchronize()
+            res.append(outs + [rm, rv, nbt])
+        for a, b in zip(*res):
+            assert torch.equal(a, b), rows
+        scale, shift, mean, invstd, rm, rv, nbt = res[0]
+        s = slab[:, :C].double().sum(0)
+        q = slab[:, cpad:cpad + C].double().sum(0)
+        m = s / count
+        var = (q / count - m * m).clamp_min(0)
+        assert int(nbt) == 1
+        eps = float(torch.tensor(1e-5, dtype=torch.float32))       # the kernel receives eps as a float
+        assert torch.allclose(mean, m.float(), rtol=3e-7, atol=1e-30) and torch.allclose(invstd, (1.0 / torch.sqrt(var + eps)).float(), rtol=3e-7, atol=0), rows
+        assert torch.allclose(scale, gamma * invstd, rtol=1e-6, atol=0) and torch.allclose(shift, beta - mean * scale, rtol=1e-5, atol=1e-6), rows
