@@ -270,3 +270,25 @@ def test_live_autograd_graph_probe_cpu():
     hooks = [p.register_post_accumulate_grad_hook(lambda p: None) for p in lin.parameters()]      # (dist.GradSync's hooks pin nothing)
     lin(torch.randn(2, 4)).sum().backward()
     assert live_autograd_graph_params(lin.parameters()) == []
+
+
+def test_pmc_record_belongs_to_the_library_in_the_tree():
+    """bench.py quotes `roofline.traffic` / `mfma_busy` from profiles/<round>/pmc_summary.json only when that record carries the
+    sha256 of the libmau_hip.so it loaded.  This test says, on the CPU, whether the committed record still belongs to the library
+    the sources build (the build is reproducible: same toolchain, same bytes); a kernel change without new records shows up here
+    as a SKIP with the reason -- bench.py then reports `traffic: null` and says why -- instead of going unnoticed."""
+    import glob
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "metadata-augmented-unet-for-lst-ndvi_amd", "libmau_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("libmau_hip.so not built")
+    have = hashlib.sha256(open(so, "rb").read()).hexdigest()
+    recs = sorted(glob.glob(os.path.join(root, "profiles", "r*", "pmc_summary.json")))
+    assert recs, "no PMC record committed under profiles/"
+    latest = json.load(open(recs[-1]))
+    assert latest and all("lib_sha256" in v for v in latest.values()), "a PMC record without the library's sha256"
+    stale = {k: v["lib_sha256"][:12] for k, v in latest.items() if v["lib_sha256"] != have}
+    if stale:
+        pytest.skip(f"{recs[-1]} was measured on another build ({stale}; this tree builds {have[:12]}): re-run scripts/r4_final.sh + r4_records2.sh")
