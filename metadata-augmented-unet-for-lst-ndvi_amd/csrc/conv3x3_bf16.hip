@@ -260,6 +260,11 @@ constexpr bool ABL_NODMA = true;
 #else
 constexpr bool ABL_NODMA = false;
 #endif
+#ifdef MAU_CONV_ABL_NOWDMA          // timing-only: the weight slabs are never moved (what weights resident in LDS would save at most)
+constexpr bool ABL_NOWDMA = true;
+#else
+constexpr bool ABL_NOWDMA = false;
+#endif
 // The same wave-DMA through a buffer resource: address = base (SGPR resource) + soff (SGPR: the stage's channel / slab
 // offset) + voff (per lane, constant over the stages of an item); a lane whose voff is 0xffffffff is out of range and
 // receives zeros (hardware range check: the zero padding of the convolution and of the slot grid, no zero page).  One
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
     unsigned char* dst_ = smem + (STAGE_) * STAGE + (wave + (J) * NW) * 1024;                                        \
     const int c0_ = (CHUNK_) * KC;                                                                                     \
     if ((J) >= HJ || wave + (J) * NW >= HALO_Q) {                                                                      \
-      dma_issue_buf(rs_w, off32[(J)], (CHUNK_) * w_stage_bytes32, dst_);                                              \
+      if (!ABL_NOWDMA) dma_issue_buf(rs_w, off32[(J)], (CHUNK_) * w_stage_bytes32, dst_);                             \
     } else if constexpr (FAST) {                                                                                       \
       if constexpr ((J) < HJ) {                                                                                        \
         if constexpr (ONE) dma_issue_buf(rs_x, off32[(J)], 2 * c0_, dst_);                                           \
