@@ -952,8 +952,12 @@ static int launch(const ConvP& p, hipStream_t st) {
   }
   const int nPixTiles = p.N * tilesX * tilesY;
   const int nCt = p.CoutPad / BN;
-  q.xcdShift = ds.xcd_shift;
-  const int nItems = round_up(nPixTiles, ds.xcds) * nCt;
+  // fewer pixel tiles than XCDs (single-tile inference at the deep levels): "every XCD owns a range of pixel tiles" would leave XCDs
+  // without work -- the items go out in plain order instead (item I = (pixel tile I / nCt, cout tile I % nCt) on XCD I % 8)
+  const bool spread = nPixTiles < ds.xcds;
+  const int xcds = spread ? 1 : ds.xcds;
+  q.xcdShift = spread ? 0 : ds.xcd_shift;
+  const int nItems = round_up(nPixTiles, xcds) * nCt;
   // persistent: as many workgroups as fit the chip at once
   const int per_cu = (int)((160 * 1024) / G::LDS) >= 2 && NW == 4 ? 2 : 1;
   int grid = ds.cus / ds.xcds * ds.xcds * per_cu;      // a multiple of the XCD count, like nItems: a workgroup stays on its XCD's slice
@@ -988,7 +992,7 @@ static int launch(const ConvP& p, hipStream_t st) {
 //  more than the overlap gained, 207 vs 182 us on the 64->64 level-0 layer; <*,8,4> = one wave per SIMD with 256
 //  accumulators in AGPRs, 0.48 instead of 0.75 fragment reads per MFMA -- 10-90 % slower, nothing hides its epilogue.)
 struct Variant {
-  int th, nw;                      // tile rows, waves per workgroup   ((32, 4) = <64,4,4>; (32, 8) = <64,2,8> | <128,4,8>)
+  int th, nw, bn;                  // tile rows, waves per workgroup, output channels per workgroup   ((32, 4, 64) = <64,4,4>; (32, 8, 64) = <64,2,8>; (32, 8, 128) = <128,4,8>)
 };
 #ifndef MAU_CONV_L0_DEFAULT
 #define MAU_CONV_L0_DEFAULT 1
@@ -996,8 +1000,14 @@ struct Variant {
 static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
   static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 64;
   const bool wide = CoutPad % 128 == 0;
+  // A 128-multiple layer whose 16-row items would keep fewer than half of the CUs busy (single-tile inference at the deep levels:
+  // 512 x 512, B = 1 gives 32 items of <128,2,8> at 32 x 32 pixels) runs on the 64-channel workgroups instead: twice the items of
+  // half the work, on twice the CUs (B = 1 conv4_0.conv2: 86 -> 45 us).  The packed weights are laid out per 64-channel block, so
+  // both widths read the same packs.  MAU_CONV_NARROW=0 switches the rule off (A/B).
+  static const bool narrow = getenv("MAU_CONV_NARROW") == nullptr || atoi(getenv("MAU_CONV_NARROW")) != 0;
+  if (wide && narrow && (long)N * ceil_div(H, 16) * ceil_div(W, TW) * (CoutPad / 128) * 2 <= device_shape().cus) return {16, 4, 64};      // <64,2,4>
   const int nCt = CoutPad / (wide ? 128 : 64);
-  Variant best = {16, wide ? 8 : 4};
+  Variant best = {16, wide ? 8 : 4, wide ? 128 : 64};
   double best_score = -1.0;
   // 64-row tiles exist for the 64-wide variant only (<64,4,8>: the per-MFMA LDS-read and DMA ratios of <128,4,8>)
   for (int th = 16; th <= (wide ? 32 : 64) && th <= th_max; th *= 2) {
@@ -1010,7 +1020,7 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
     const double score = grid_fill * tile_fill * (th == 64 ? 1.10 : th == 32 ? 1.06 : 1.0);
     if (score > best_score) {
       best_score = score;
-      best = {th, nw};
+      best = {th, nw, wide ? 128 : 64};
     }
   }
   // Level 0 (64 output channels, the 64-row tile wins the score): TWO independent 4-wave workgroups per CU, each on a 32 x 16 pixel
@@ -1019,7 +1029,7 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
   // workgroup are in it together); two workgroups drift apart, one's epilogue runs beside the other's multiply loop.  Costs: the weight
   // slab is fetched by both (L2 hits; 74 instead of 55 DMA bytes per pixel).  MAU_CONV_L0: 1 = on, 0 = off (A/B).
   static const int l0 = getenv("MAU_CONV_L0") ? atoi(getenv("MAU_CONV_L0")) : MAU_CONV_L0_DEFAULT;
-  if (l0 && !wide && best.th == 64 && th_max >= 64) best = {32, 4};
+  if (l0 && !wide && best.th == 64 && th_max >= 64) best = {32, 4, 64};
   return best;
 }
 }  // namespace v2
@@ -1031,28 +1041,28 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
 #define MAU_CONV_TU_NAME2(e, f) launch_conv_bf16_tu_e##e##_f##f
 #define MAU_CONV_TU_NAME(e, f) MAU_CONV_TU_NAME2(e, f)
 #ifdef MAU_CONV_TU_EPI
-int MAU_CONV_TU_NAME(MAU_CONV_TU_EPI, MAU_CONV_TU_F16)(const ConvP& p, int th, int nw, hipStream_t st) {
+int MAU_CONV_TU_NAME(MAU_CONV_TU_EPI, MAU_CONV_TU_F16)(const ConvP& p, int th, int nw, int bn, hipStream_t st) {
   constexpr int E = MAU_CONV_TU_EPI;
   constexpr bool F = MAU_CONV_TU_F16 != 0;
-  if (p.CoutPad % 128 == 0) return th == 32 ? v2::launch<128, 4, 8, E, F>(p, st) : v2::launch<128, 2, 8, E, F>(p, st);
+  if (bn == 128) return th == 32 ? v2::launch<128, 4, 8, E, F>(p, st) : v2::launch<128, 2, 8, E, F>(p, st);
   if (th == 64) return v2::launch<64, 4, 8, E, F>(p, st);
   if (th == 32 && nw == 4) return v2::launch<64, 4, 4, E, F>(p, st);
   return th == 32 ? v2::launch<64, 2, 8, E, F>(p, st) : v2::launch<64, 2, 4, E, F>(p, st);
 }
 #else
-int launch_conv_bf16_tu_e0_f0(const ConvP&, int, int, hipStream_t);
-int launch_conv_bf16_tu_e1_f0(const ConvP&, int, int, hipStream_t);
-int launch_conv_bf16_tu_e2_f0(const ConvP&, int, int, hipStream_t);
-int launch_conv_bf16_tu_e0_f1(const ConvP&, int, int, hipStream_t);
-int launch_conv_bf16_tu_e1_f1(const ConvP&, int, int, hipStream_t);
-int launch_conv_bf16_tu_e2_f1(const ConvP&, int, int, hipStream_t);
+int launch_conv_bf16_tu_e0_f0(const ConvP&, int, int, int, hipStream_t);
+int launch_conv_bf16_tu_e1_f0(const ConvP&, int, int, int, hipStream_t);
+int launch_conv_bf16_tu_e2_f0(const ConvP&, int, int, int, hipStream_t);
+int launch_conv_bf16_tu_e0_f1(const ConvP&, int, int, int, hipStream_t);
+int launch_conv_bf16_tu_e1_f1(const ConvP&, int, int, int, hipStream_t);
+int launch_conv_bf16_tu_e2_f1(const ConvP&, int, int, int, hipStream_t);
 
 // rows of the BatchNorm partial-sum slab: one per (pixel tile, wave row of the workgroup)
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   const int CoutPad = round_up(Cout, 64);
   const v2::Variant v = v2::pick_variant(CoutPad, N, H, W);
   const int th = v.th;
-  const int wm = (CoutPad % 128 != 0 && v.nw == 8) ? v2::Geo<64, 2, 8>::WM : 4;    // <128,*,8>, <64,2,4>, <64,4,4>: 4 wave rows; <64,2,8>, <64,4,8>: 8
+  const int wm = (v.bn == 64 && v.nw == 8) ? v2::Geo<64, 2, 8>::WM : 4;    // <128,*,8>, <64,2,4>, <64,4,4>: 4 wave rows; <64,2,8>, <64,4,8>: 8
   static_assert(v2::Geo<64, 4, 4>::WM == 4 && v2::Geo<64, 4, 4>::TH == 32, "slab rows");
   static_assert(v2::Geo<64, 2, 8>::WM == 8 && v2::Geo<64, 4, 8>::WM == 8 && v2::Geo<64, 4, 8>::TH == 64, "slab rows");
   static_assert(v2::Geo<128, 2, 8>::WM == 4 && v2::Geo<128, 4, 8>::WM == 4 && v2::Geo<64, 2, 4>::WM == 4, "slab rows");
@@ -1066,10 +1076,10 @@ int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
   }
   static_assert(v2::EPI_PLAIN == 0 && v2::EPI_STATS == 1 && v2::EPI_POST == 2, "translation-unit names");
   const v2::Variant v = v2::pick_variant(p.CoutPad, p.N, p.H, p.W);
-  const int th = v.th, nw = v.nw;
-  if (p.post_scale != nullptr) return f16 ? launch_conv_bf16_tu_e2_f1(p, th, nw, st) : launch_conv_bf16_tu_e2_f0(p, th, nw, st);   // (a post-affine launch carries no slab)
-  if (p.slab != nullptr) return f16 ? launch_conv_bf16_tu_e1_f1(p, th, nw, st) : launch_conv_bf16_tu_e1_f0(p, th, nw, st);
-  return f16 ? launch_conv_bf16_tu_e0_f1(p, th, nw, st) : launch_conv_bf16_tu_e0_f0(p, th, nw, st);
+  const int th = v.th, nw = v.nw, bn = v.bn;
+  if (p.post_scale != nullptr) return f16 ? launch_conv_bf16_tu_e2_f1(p, th, nw, bn, st) : launch_conv_bf16_tu_e2_f0(p, th, nw, bn, st);   // (a post-affine launch carries no slab)
+  if (p.slab != nullptr) return f16 ? launch_conv_bf16_tu_e1_f1(p, th, nw, bn, st) : launch_conv_bf16_tu_e1_f0(p, th, nw, bn, st);
+  return f16 ? launch_conv_bf16_tu_e0_f1(p, th, nw, bn, st) : launch_conv_bf16_tu_e0_f0(p, th, nw, bn, st);
 }
 #endif
 
