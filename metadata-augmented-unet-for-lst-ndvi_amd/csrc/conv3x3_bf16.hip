@@ -1,7 +1,7 @@
 // conv3x3_bf16.hip -- the throughput kernel: 16-bit (bf16 / fp16) 3x3 convolution, forward and data gradient, as an
 // im2col-free implicit GEMM on the gfx950 matrix cores.
 //
-//   workgroup : TH x 16 output pixels (TH = 16 | 32 | 64) x BN output channels (64 | 128), 4 or 8 waves (Geo<BN, MT, NW>);
+//   workgroup : TH x 16 output pixels (TH = 8 | 16 | 32 | 64) x BN output channels (64 | 128), 4 or 8 waves (Geo<BN, MT, NW>);
 //               persistent, 1-D grid; every XCD owns a contiguous range of pixel tiles (image order) and runs the cout tiles of
 //               one pixel tile back to back: its L2 serves halo overlap and input re-reads (pure speed)
 //   wave      : MT x 32 pixels x 64 channels; 64 or 128 fp32 accumulator registers
@@ -20,7 +20,7 @@
 //               lane groups are conflict-free as they are)
 //   epilogue  : bias, BatchNorm partial statistics from the fp32 accumulators, or the inference affine + ReLU; 16-bit
 //               conversion, output tile staged through LDS and stored as whole 128-byte pixel rows
-//   build     : 72 instantiations; one (epilogue, operand type) slice per translation unit -- see "translation units" below
+//   build     : 120 instantiations; one (epilogue, operand type) slice per translation unit -- see "translation units" below
 //
 // Replaces nn.Conv2d(.,.,3,padding=1) + the statistics half of nn.BatchNorm2d of VGGBlock
 // (reference src/model.py:12-15), torch.cat([skip, up]) (:279-282) and fuse_embeddings (:248-259).
@@ -196,6 +196,7 @@ struct Item {
 // MT x 32 pixels (MT x 2 tile rows of 16) x 64 channels = MT x 2 accumulator tiles of 32x32.
 //   <128, 2, 8>: 16x16 px tile     <128, 4, 8>: 32x16 px tile (128 accumulator registers per lane)
 //   < 64, 2, 4>: 16x16             < 64, 2, 8>: 32x16             < 64, 4, 8>: 64x16 px tile (128 accumulator registers)
+//   < 64, 4, 4>: 32x16 (two workgroups per CU)                      < 64, 1, 4>:  8x16 (under-filled layers: single-tile inference)
 // Larger tiles move fewer LDS-DMA bytes per MFMA (weights are shared by more pixels, the halo by more
 // channels): the ablation in DESIGN.md prices each DMA stream at ~12 % of the kernel time.
 template <int BN, int MT, int NW>
@@ -1005,7 +1006,12 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
   // half the work, on twice the CUs (B = 1 conv4_0.conv2: 86 -> 45 us).  The packed weights are laid out per 64-channel block, so
   // both widths read the same packs.  MAU_CONV_NARROW=0 switches the rule off (A/B).
   static const bool narrow = getenv("MAU_CONV_NARROW") == nullptr || atoi(getenv("MAU_CONV_NARROW")) != 0;
-  if (wide && narrow && (long)N * ceil_div(H, 16) * ceil_div(W, TW) * (CoutPad / 128) * 2 <= device_shape().cus) return {16, 4, 64};      // <64,2,4>
+  if (wide && narrow) {
+    const long tiles16 = (long)N * ceil_div(H, 16) * ceil_div(W, TW);
+    // (... and 8-row tiles <64,1,4> while even those items are fewer than half of the CUs: the chain of one wave halves again)
+    if (tiles16 * (CoutPad / 64) * 2 <= device_shape().cus) return {8, 4, 64};        // <64,1,4>
+    if (tiles16 * (CoutPad / 128) * 2 <= device_shape().cus) return {16, 4, 64};      // <64,2,4>
+  }
   const int nCt = CoutPad / (wide ? 128 : 64);
   Variant best = {16, wide ? 8 : 4, wide ? 128 : 64};
   double best_score = -1.0;
@@ -1035,7 +1041,7 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
 }  // namespace v2
 
 // ---- translation units ----
-// The kernel has 72 instantiations (5 tile variants x 2 loaders + 2 stage-pair variants, x 3 epilogues x 2 operand types) of
+// The kernel has 120 instantiations (7 tile variants x 2 loaders + 3 big-tile variants x 2 stage-pair forms, x 3 epilogues x 2 operand types) of
 // 4-5 s each: one (epilogue, operand type) slice per translation unit (conv3x3_bf16_e<EPI>_<type>.hip define MAU_CONV_TU_EPI /
 // MAU_CONV_TU_F16 and include this file), built in parallel; this file alone carries the variant choice and the dispatcher.
 #define MAU_CONV_TU_NAME2(e, f) launch_conv_bf16_tu_e##e##_f##f
@@ -1045,6 +1051,7 @@ int MAU_CONV_TU_NAME(MAU_CONV_TU_EPI, MAU_CONV_TU_F16)(const ConvP& p, int th, i
   constexpr int E = MAU_CONV_TU_EPI;
   constexpr bool F = MAU_CONV_TU_F16 != 0;
   if (bn == 128) return th == 32 ? v2::launch<128, 4, 8, E, F>(p, st) : v2::launch<128, 2, 8, E, F>(p, st);
+  if (th == 8) return v2::launch<64, 1, 4, E, F>(p, st);
   if (th == 64) return v2::launch<64, 4, 8, E, F>(p, st);
   if (th == 32 && nw == 4) return v2::launch<64, 4, 4, E, F>(p, st);
   return th == 32 ? v2::launch<64, 2, 8, E, F>(p, st) : v2::launch<64, 2, 4, E, F>(p, st);
@@ -1066,6 +1073,7 @@ int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   static_assert(v2::Geo<64, 4, 4>::WM == 4 && v2::Geo<64, 4, 4>::TH == 32, "slab rows");
   static_assert(v2::Geo<64, 2, 8>::WM == 8 && v2::Geo<64, 4, 8>::WM == 8 && v2::Geo<64, 4, 8>::TH == 64, "slab rows");
   static_assert(v2::Geo<128, 2, 8>::WM == 4 && v2::Geo<128, 4, 8>::WM == 4 && v2::Geo<64, 2, 4>::WM == 4, "slab rows");
+  static_assert(v2::Geo<64, 1, 4>::WM == 4 && v2::Geo<64, 1, 4>::TH == 8, "slab rows");
   return wm * N * ceil_div(H, th) * ceil_div(W, v2::TW);
 }
 
