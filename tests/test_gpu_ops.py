@@ -68,7 +68,10 @@ def _exact_int_case(g, N, Cin, Cout, H, W):
                                    (3, 200, 72, 20, 34),
                                    # more work items than persistent workgroups (several items per workgroup, cross-item
                                    # prefetch), 32-row tiles with ragged bottom/right edges, 1-chunk K loops, 2-3 cout tiles
-                                   (6, 24, 130, 70, 100), (8, 64, 256, 96, 112), (12, 6, 64, 100, 100), (3, 40, 128, 33, 17)])
+                                   (6, 24, 130, 70, 100), (8, 64, 256, 96, 112), (12, 6, 64, 100, 100), (3, 40, 128, 33, 17),
+                                   # 128-multiple layers that would leave most CUs idle: 64-channel workgroups on 8- / 16-row tiles
+                                   # (<64,1,4>, <64,2,4>), fewer pixel tiles than XCDs (plain item order), ragged in both directions
+                                   (1, 16, 256, 12, 20), (2, 32, 384, 9, 16), (1, 48, 1024, 32, 32), (4, 16, 128, 30, 50)])
 def test_conv3x3_exact_integers(mau, dt, shape):
     """Small-integer data is exact in bf16 and fp32: the MFMA operand/accumulator lane maps, halo
     handling and edge masking must reproduce torch's conv2d bit for bit (asymmetric weights)."""
@@ -106,7 +109,8 @@ def test_conv3x3_exact_integers(mau, dt, shape):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 6, 16, 8, 16), (1, 23, 40, 19, 21), (2, 72, 130, 9, 33), (3, 64, 128, 24, 40),
                                    (2, 136, 256, 16, 16), (1, 3, 5, 2, 3), (4, 8, 8, 3, 3), (9, 1, 1, 1, 1), (2, 17, 70, 5, 40),
-                                   (6, 24, 130, 70, 100), (8, 64, 256, 96, 112), (3, 40, 128, 33, 17)])
+                                   (6, 24, 130, 70, 100), (8, 64, 256, 96, 112), (3, 40, 128, 33, 17),
+                                   (2, 128, 32, 16, 16), (1, 256, 16, 12, 20), (1, 1024, 48, 32, 32)])     # data gradient onto a 128-multiple of channels, few items
 def test_conv3x3_dgrad_wgrad_exact_integers(mau, dt, shape):
     from mau_amd import functional as F_
     from mau_amd._lib import call, lib
