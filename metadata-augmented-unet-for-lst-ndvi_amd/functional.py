@@ -305,6 +305,7 @@ class BNState:
     up_to: object = None                  # None | (H, W): return the bilinear (align_corners=True) resize of the activation
     first: bool = False                   # x is the network input (N, C, H, W) fp32, C <= 8: the first-layer kernel reads it as it is
     dtype: object = None                  # activation dtype of the network (first=True: x itself is fp32)
+    dgrad_first: bool = False             # backward: enqueue the data gradient before the weight-gradient branch's kernel (model._Runtime)
 
 
 def _all_reduce_(t: torch.Tensor, st: BNState):
@@ -351,6 +352,10 @@ def _join_side_when_backward_ends(dev):
         torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
 
     torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
+# launch order inside ConvBNReLU.backward: None = the network's choice (BNState.dgrad_first), "0" / "1" = forced (same-call A/B)
+_DGRAD_FIRST = os.environ.get("MAU_BWD_DGRAD_FIRST")
 
 
 def _conv_fwd(x, x1, st, emb, emb_ws, E, wpk, bias, post, y, Cout, slab, code, N, H, W, stream):
@@ -699,8 +704,20 @@ class ConvBNReLU(torch.autograd.Function):
         overlap = _OVERLAP_WGRAD
         side = _side_stream(dev) if (needs[3] and overlap and (need_dx or overlap >= 2)) else None
         deferred = False
+        dfull = None
+        if (st.dgrad_first if _DGRAD_FIRST is None else _DGRAD_FIRST == "1") and need_dx and needs[3] and side is not None:
+            # the main chain's data gradient is enqueued BEFORE the branch's weight gradient (both need only dy: whichever is
+            # enqueued first takes the chip, the other follows when its workgroups retire); the branch still waits only for dy --
+            # the event is recorded in front of the data gradient.  Which order is faster depends on the network (model._Runtime).
+            dy_ready = torch.cuda.Event()
+            dy_ready.record()
+            wd = ctx.wd if ctx.wd is not None else pack_conv_weights(weight, code, forward=False, dgrad=True)[1]
+            dfull = torch.empty((N, H, W, pad8(Cin)), dtype=y.dtype, device=dev)
+            call("mau_conv3x3_fwd", dy.data_ptr(), ldy, Cout, None, None, 0, wd.data_ptr(), None, None, None, dfull.data_ptr(),
+                 pad8(Cin), Cin, None, code, N, H, W, stream)
+            side.wait_event(dy_ready)
         if needs[3]:
-            if side is not None:
+            if side is not None and dfull is None:
                 side.wait_stream(torch.cuda.current_stream())           # dy is complete
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 # (workspaces of the side stream's kernels belong to ITS allocator pool: freed here, re-used there)
@@ -737,9 +754,10 @@ class ConvBNReLU(torch.autograd.Function):
         if need_dx:
             wd = ctx.wd if ctx.wd is not None else pack_conv_weights(weight, code, forward=False, dgrad=True)[1]
             ldd = pad8(Cin)
-            dfull = torch.empty((N, H, W, ldd), dtype=y.dtype, device=dev)
-            call("mau_conv3x3_fwd", dy.data_ptr(), ldy, Cout, None, None, 0, wd.data_ptr(), None, None, None, dfull.data_ptr(),
-                 ldd, Cin, None, code, N, H, W, stream)
+            if dfull is None:
+                dfull = torch.empty((N, H, W, ldd), dtype=y.dtype, device=dev)
+                call("mau_conv3x3_fwd", dy.data_ptr(), ldy, Cout, None, None, 0, wd.data_ptr(), None, None, None, dfull.data_ptr(),
+                     ldd, Cin, None, code, N, H, W, stream)
             Ct = st.C0 + C1
             if E and needs[2]:
                 demb = torch.empty((N, E), **f32)

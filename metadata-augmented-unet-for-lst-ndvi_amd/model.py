@@ -51,6 +51,10 @@ class _Runtime:
         self.group = None
         self.world = 1
         self.comm = None                  # dist.RcclComm for the SyncBN messages (None: local BN, or a group that is not on RCCL)
+        # launch order inside a block's backward (functional.ConvBNReLU.backward): False = the weight-gradient branch's kernel is
+        # enqueued before the main chain's data gradient, True = after it.  Measured per network ("launch order"):
+        # the U-Net is 0.6 % faster with False, the U-Net++ 1.2 % faster with True; MAU_BWD_DGRAD_FIRST=0/1 overrides both.
+        self.dgrad_first = False
 
     @property
     def dtype(self) -> torch.dtype:
@@ -87,7 +91,8 @@ class VGGBlock(nn.Module):
                      group=rt.group, comm=rt.comm, world=rt.world, grad_enabled=torch.is_grad_enabled(),
                      frozen=None if self._frozen is None else self._frozen[0 if conv is self.conv1 else 1],
                      C1=0 if x1 is None else x1.C, pool=pool, out_view=out_view,
-                     head=None if head is None else bool(head_act), up_to=up_to, first=x.nchw, dtype=rt.dtype if x.nchw else None)
+                     head=None if head is None else bool(head_act), up_to=up_to, first=x.nchw, dtype=rt.dtype if x.nchw else None,
+                     dgrad_first=rt.dgrad_first)
         # (``weight``: a tensor DERIVED from conv.weight that the convolution runs on instead -- functional.EmbFold's W_eff)
         t = F_.ConvBNReLU.apply(x.t, None if x1 is None else x1.t, emb, conv.weight if weight is None else weight, conv.bias, bn.weight, bn.bias,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked,
@@ -425,6 +430,7 @@ class UrbanPredictor_unetpp(_NetBase):
     def __init__(self, spatial_channels, seq_len, temporal_dim, meta_features, meta_dim, lstm_dim, out_channels,
                  base_filters=32, deep_supervision=False, **kwargs):
         super().__init__()
+        self._rt.dgrad_first = True           # (launch order of a block's backward: _Runtime.dgrad_first)
         nb = [base_filters, base_filters * 2, base_filters * 4, base_filters * 8, base_filters * 16]
         self.deep_supervision = deep_supervision
         self.pool = nn.MaxPool2d(2, 2)
