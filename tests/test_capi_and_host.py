@@ -39,7 +39,11 @@ def test_library_exports_every_header_symbol():
     # tiles when the layer is small (slab rows = workgroup tiles x wave rows per workgroup)
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 256, 256, 64) == 32 * 4 * 16 * 8
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 32, 32, 256) == 32 * 2 * 2 * 4
-    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 2, 16, 16, 1024) == 2 * 4
+    # a 128-multiple layer that would leave most CUs idle runs on 64-channel workgroups: 8-row tiles while even their items are fewer
+    # than half of the CUs (2 images x 2 x 1 tiles x 4 wave rows), 16-row tiles otherwise (16 images x 1 x 1 x 4)
+    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 2, 16, 16, 1024) == 2 * 2 * 4
+    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 16, 16, 16, 1024) == 16 * 4
+    assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 16, 16, 1024) == 32 * 4
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 16, 16, 1024) == 32 * 4
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_F32, 2, 250, 250, 64) == 2 * 32 * 16
     s = _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 32, 32, 512, 1536)
