@@ -162,8 +162,15 @@ def cpu_baseline(iters=5, warmup=2):
 
 STAGE_TAG = "[mau-bench-stage]"
 # seconds without a NEW stage line before a worker counts as hung (stage it is in -> limit).  Generous where a slow host decides
-# (first `import torch` on a fresh box: 1-2 min; rendezvous waits for the slowest rank), tight where a broken capture would hang.
-STAGE_LIMITS = {"spawned": 420, "imported": 420, "ready": 240, "warm": 180, "captured": 180, "timed": 420, "done": 120}
+# (first `import torch` on a fresh box: 1-2 min; rendezvous waits for the slowest rank), tight where a broken capture or a
+# mis-ordered collective would hang: `captured` = the timed regions (~10-25 s of GPU work), `timed` = the per-kernel event pass
+# and the forward latency after them (seconds).  Every limit is additionally clipped to what is left of the run's budget.
+STAGE_LIMITS = {"spawned": 300, "imported": 300, "ready": 150, "warm": 120, "captured": 120, "timed": 120, "done": 60}
+# One budget for the whole N > 1 measurement, all attempts together (the driver ends the run at 600 s): an attempt is only
+# started with enough of it left for itself (MIN_ATTEMPT_S: fresh workers, import, warm-up, ~10 s of timed regions), and a
+# non-final attempt is cut off early enough to leave that much for the most conservative one.
+BUDGET_S = float(os.environ.get("MAU_BENCH_BUDGET_S", "540"))
+MIN_ATTEMPT_S = float(os.environ.get("MAU_BENCH_MIN_ATTEMPT_S", "100"))
 
 
 def stage(name):
@@ -179,12 +186,17 @@ def _free_port():
         return sock.getsockname()[1]
 
 
-def supervise_workers(cmds_envs, limits=None, poll=0.2, log=sys.stderr):
+def _metric_lines(out):
+    return [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+
+
+def supervise_workers(cmds_envs, limits=None, poll=0.2, log=sys.stderr, deadline=None, abort=None):
     """Run one attempt: start every (cmd, env) as a child in its own session, relay their stderr, watch their stage lines.
     Returns (ok, stdout of worker 0).  ok = every worker reported `done` (after which its exit code no longer matters:
     the result line is out and the ranks have passed their last barrier) or exited 0.  On the first failure -- a non-zero
-    exit before `done`, or no new stage line within the stage's limit -- ALL workers of the attempt are killed (SIGKILL to
-    their sessions: a rank hung in a collective ignores anything gentler)."""
+    exit before `done`, no new stage line within the stage's limit, the attempt's ``deadline`` (time.monotonic()) passing,
+    or ``abort()`` turning true (another rank's supervisor saw ITS worker fail) -- ALL workers of the attempt are killed
+    (SIGKILL to their sessions: a rank hung in a collective ignores anything gentler)."""
     import signal
     import subprocess
     import threading
@@ -210,12 +222,13 @@ def supervise_workers(cmds_envs, limits=None, poll=0.2, log=sys.stderr):
     failure = None
     while failure is None:
         alive = False
+        now = time.monotonic()
         for i, p in enumerate(procs):
             rc = p.poll()
             st = state[i]
             if rc is None:
                 alive = True
-                if time.monotonic() - st["t"] > limits.get(st["stage"], 240) * scale:
+                if now - st["t"] > limits.get(st["stage"], 240) * scale:
                     if st["stage"] == "done":             # result out, last barrier passed: a rank stuck in its teardown is just ended
                         try:
                             os.killpg(p.pid, signal.SIGKILL)
@@ -227,6 +240,11 @@ def supervise_workers(cmds_envs, limits=None, poll=0.2, log=sys.stderr):
                 failure = f"worker {i} exited with code {rc} in stage '{st['stage']}'"
         if not alive:
             break
+        pending = [i for i, p in enumerate(procs) if p.poll() is None and state[i]["stage"] != "done"]
+        if failure is None and pending and deadline is not None and now > deadline:
+            failure = f"the attempt ran out of its share of the {BUDGET_S:.0f} s budget (worker {pending[0]} in stage '{state[pending[0]]['stage']}')"
+        if failure is None and pending and abort is not None and abort():
+            failure = "another rank's supervisor reported a failed worker"
         time.sleep(poll)
     if failure is not None:
         print(f"bench.py supervisor: {failure}; killing this attempt's workers", file=log, flush=True)
@@ -245,41 +263,174 @@ def supervise_workers(cmds_envs, limits=None, poll=0.2, log=sys.stderr):
     return failure is None, "".join(state[0]["out"]) if state else ""
 
 
-def run_supervised(make_attempt, log=sys.stderr):
-    """Attempt 1: captured data-parallel step (MAU_DP_GRAPH=1) unless the environment pins the mode; attempt 2 (only after a
+class NodeCoordinator:
+    """How the rank supervisors of ONE node (the processes torch.distributed.run started) stay in step without a collective
+    and without the launcher's store (it has no per-attempt key space: the addresses a failed attempt leaves there poison
+    the next one).  A directory named after the launcher (the parent of every rank it started: pid + start time) holds
+      <seq>.plan    written by the LEADER (local rank 0): "<plan index> <port>" for attempt number seq, or "stop <rc>";
+      <seq>.failed  touched by ANY supervisor whose worker failed in attempt seq: the others end theirs at once instead of
+                    waiting for the stage limit of a worker hung in a collective with a dead peer;
+      ack.<rank>    a follower has read the leader's "stop".
+    Only the leader decides which attempt runs next (its clock, its budget); followers wait for the next plan for as long as
+    the run's budget lasts (an early failure on one rank never times out against a peer that is still waiting for its own
+    worker's stage limit).  The leader removes the directory when it leaves; a follower that finds it gone stops too."""
+
+    def __init__(self):
+        import tempfile
+        ppid = os.getppid()
+        try:                      # the launcher's start time (clock ticks since boot) tells two launchers apart that got the same pid
+            with open(f"/proc/{ppid}/stat") as f:
+                born = f.read().rsplit(")", 1)[1].split()[19]
+        except (OSError, IndexError):
+            born = "0"
+        self.dir = os.path.join(tempfile.gettempdir(), f"mau_bench_{ppid}_{born}_{os.environ.get('MASTER_PORT', '0')}")
+        self.local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+        self.n_local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        self.leader = self.local_rank == 0
+        self.seen = False
+        if self.leader:
+            os.makedirs(self.dir, exist_ok=True)
+            for f in os.listdir(self.dir):            # (a launcher pid + start time + port cannot repeat; belt and braces)
+                self._unlink(f)
+
+    def _unlink(self, name):
+        try:
+            os.unlink(os.path.join(self.dir, name))
+        except OSError:
+            pass
+
+    def _write(self, name, text):
+        try:
+            tmp = os.path.join(self.dir, f".{name}.{os.getpid()}.tmp")
+            with open(tmp, "w") as f:
+                f.write(text)
+            os.replace(tmp, os.path.join(self.dir, name))
+        except OSError:
+            pass                                       # (a follower writing into a directory the leader has just removed)
+
+    def announce(self, seq, k, port):
+        self._write(f"{seq}.plan", f"{k} {port}")
+
+    def stop(self, seq, rc, wait=5.0):
+        """Leader: tell the followers the run is over, give them a moment to read it, remove the directory."""
+        self._write(f"{seq}.plan", f"stop {rc}")
+        t0 = time.monotonic()
+        while time.monotonic() - t0 < wait:
+            try:
+                acks = sum(1 for f in os.listdir(self.dir) if f.startswith("ack."))
+            except OSError:
+                break
+            if acks >= self.n_local - 1:
+                break
+            time.sleep(0.05)
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+    def await_plan(self, seq, deadline):
+        """Follower: ("run", k, port) | ("stop", rc).  The directory vanishing after it was seen = the leader has left."""
+        path = os.path.join(self.dir, f"{seq}.plan")
+        while time.monotonic() < deadline:
+            try:
+                with open(path) as f:
+                    a, b = f.read().split()
+                if a == "stop":
+                    self._write(f"ack.{self.local_rank}", "")
+                    return ("stop", int(b))
+                return ("run", int(a), int(b))
+            except (OSError, ValueError):
+                if os.path.isdir(self.dir):
+                    self.seen = True
+                elif self.seen:
+                    return ("stop", 0)
+                time.sleep(0.05)
+        return ("stop", 1)
+
+    def flag_failure(self, seq):
+        self._write(f"{seq}.failed", "")
+
+    def failed(self, seq):
+        return os.path.exists(os.path.join(self.dir, f"{seq}.failed"))
+
+
+def run_supervised(make_attempt, log=sys.stderr, coord=None, budget=None):
+    """The N > 1 measurement under ONE time budget (``MAU_BENCH_BUDGET_S``, default 540 s; the driver's limit is 600).
+    Attempt 1: captured data-parallel step (MAU_DP_GRAPH=1) unless the environment pins the mode; attempt 2 (only after a
     failed attempt 1): eager step, fresh workers, fresh rendezvous; attempt 3 (only after a failed attempt 2, and unless the
     environment pins MAU_RCCL_DIRECT): the eager step with every collective through ProcessGroupNCCL (MAU_RCCL_DIRECT=0, round
-    3's path: slower, but the one torch itself exercises everywhere).  ``make_attempt(k, dp_graph)`` -> list of (cmd, env).
-    Prints the surviving attempt's JSON line -- its ``config.launch`` / ``config.collectives`` say which attempt that was;
-    exit code 0 iff one attempt succeeded."""
+    3's path: slower, but the one torch itself exercises everywhere).  ``make_attempt(k, dp_graph, port)`` -> list of (cmd, env).
+    Budget rules: an attempt starts only with MIN_ATTEMPT_S of the budget left; with less than two of them left the plan jumps
+    to its LAST entry (the most conservative attempt); a non-final attempt is ended MIN_ATTEMPT_S before the budget's end.
+    A result line that worker 0 has already printed is never lost: rank 0 prints one as soon as the timed regions are over
+    (before the per-kernel event pass) and again, complete, at the end -- the last line in hand is printed even when the
+    attempt failed afterwards.  Prints that ONE JSON line -- its ``config.launch`` / ``config.collectives`` say which attempt
+    produced it; exit code 0 iff a line was printed (on the rank that holds worker 0) or the leader said so (``coord``)."""
+    t_start = time.monotonic()
+    scale = float(os.environ.get("MAU_BENCH_STALL_SCALE", "1"))
+    budget = (BUDGET_S if budget is None else budget) * scale
+    min_attempt = MIN_ATTEMPT_S * scale
+    deadline = t_start + budget
     pinned = os.environ.get("MAU_DP_GRAPH")
     plan = [(pinned == "1", {})] if pinned in ("0", "1") else [(True, {}), (False, {})]
     if os.environ.get("MAU_RCCL_DIRECT") is None and not plan[-1][0]:
         plan.append((False, {"MAU_RCCL_DIRECT": "0"}))
     what = {True: "captured data-parallel step", False: "eager data-parallel step"}
-    for k, (dp_graph, extra) in enumerate(plan):
-        attempt = [(cmd, dict(env, **extra)) for cmd, env in make_attempt(k, dp_graph)]
-        ok, out = supervise_workers(attempt, log=log)
-        lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    leader = coord is None or coord.leader
+    k, seq, rc = 0, 0, 1
+    while True:
+        if leader:
+            left = deadline - time.monotonic()
+            if k >= len(plan) or left < min_attempt:
+                if k < len(plan):
+                    print(f"bench.py supervisor: {left:.0f} s of the {budget:.0f} s budget left: no further attempt", file=log, flush=True)
+                break
+            if k < len(plan) - 1 and left < 2 * min_attempt:
+                print(f"bench.py supervisor: {left:.0f} s of the budget left: skipping to the most conservative attempt", file=log, flush=True)
+                k = len(plan) - 1
+            port = _free_port()
+            if coord is not None:
+                coord.announce(seq, k, port)
+        else:
+            got = coord.await_plan(seq, deadline + 30.0 * scale)
+            if got[0] == "stop":
+                return got[1]
+            _, k, port = got
+        dp_graph, extra = plan[k]
+        if seq > 0:
+            print(f"bench.py supervisor: falling back to the {what[dp_graph]}" + (" over ProcessGroupNCCL" if extra else "") + " with fresh workers",
+                  file=log, flush=True)
+        attempt = [(cmd, dict(env, **extra)) for cmd, env in make_attempt(k, dp_graph, port)]
+        last = k == len(plan) - 1
+        ok, out = supervise_workers(attempt, log=log, deadline=deadline - (0.0 if last else min_attempt),
+                                    abort=(lambda s=seq: coord.failed(s)) if coord is not None else None)
+        if not ok and coord is not None:
+            coord.flag_failure(seq)
+        lines = _metric_lines(out)
         for ln in out.splitlines():
             if ln not in lines:
                 print(ln, file=log)
-        if ok:
-            if lines:
-                print(lines[-1], flush=True)
-            return 0
-        if k + 1 < len(plan):
-            nxt = plan[k + 1]
-            print(f"bench.py supervisor: falling back to the {what[nxt[0]]}" + (" over ProcessGroupNCCL" if nxt[1] else "") + " with fresh workers",
-                  file=log, flush=True)
-    return 1
+        if lines:                                     # (only the supervisor of worker 0 ever holds one)
+            if not ok:
+                print("bench.py supervisor: the attempt failed AFTER its timed regions; the result line it had printed stands", file=log, flush=True)
+            print(lines[-1], flush=True)
+            rc = 0
+            break
+        if ok and leader:                             # (no worker 0 here, or a stand-in that prints nothing)
+            rc = 0
+            break
+        if ok and not leader:                         # this rank is through; the leader says how the run ended
+            seq += 1
+            got = coord.await_plan(seq, deadline + 30.0 * scale)
+            return got[1] if got[0] == "stop" else 1
+        k, seq = k + 1, seq + 1
+    if coord is not None and leader:
+        coord.stop(seq + 1 if rc == 0 else seq, rc)
+    return rc
 
 
 def self_launch(args, argv):
     """``python bench.py --gpus N`` (N > 1) outside torch.distributed.run: this process -- it has not touched the GPU and never
     execs -- is the supervisor of all N ranks."""
-    def make_attempt(k, dp_graph):
-        port = _free_port()
+    def make_attempt(k, dp_graph, port):
         out = []
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
@@ -292,47 +443,22 @@ def self_launch(args, argv):
     raise SystemExit(run_supervised(make_attempt))
 
 
-def _agree_on_port(attempt: int, timeout: float = 120.0) -> int:
-    """A fresh rendezvous port for one attempt's workers, agreed between the rank supervisors of ONE node without a collective:
-    the supervisor of local rank 0 picks a free port and publishes it in a file named after the launcher's pid (the parent of
-    every rank it started) and the attempt; the others wait for the file.  The launcher's own store is not used for the
-    workers: it has no per-attempt key space, so the addresses a failed attempt left there would poison the next one."""
-    import tempfile
-    ppid = os.getppid()
-    try:                      # the launcher's start time (clock ticks since boot) tells two launchers apart that got the same pid
-        with open(f"/proc/{ppid}/stat") as f:
-            born = f.read().rsplit(")", 1)[1].split()[19]
-    except (OSError, IndexError):
-        born = "0"
-    path = os.path.join(tempfile.gettempdir(), f"mau_bench_{ppid}_{born}_{os.environ.get('MASTER_PORT', '0')}_{attempt}.port")
-    if int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))) == 0:
-        port = _free_port()
-        with open(path + ".tmp", "w") as f:
-            f.write(str(port))
-        os.replace(path + ".tmp", path)
-        return port
-    t0 = time.monotonic()
-    while time.monotonic() - t0 < timeout:
-        try:
-            with open(path) as f:
-                return int(f.read())
-        except (OSError, ValueError):
-            time.sleep(0.05)
-    raise SystemExit(f"bench.py supervisor: rank 0's supervisor never published the port of attempt {attempt} ({path})")
-
-
 def rank_supervisor(argv):
     """Under torch.distributed.run (RANK / WORLD_SIZE set by the launcher): this launched process stays off the GPU and supervises
-    ONE worker -- its rank.  Every rank's supervisor applies the same rule, so a failed attempt 1 ends on every rank (a rank
-    that lost a peer hangs in its next collective and is killed at the stage limit) and attempt 2's workers meet on a fresh
-    rendezvous (rank 0 of the workers hosts a store on a port of the attempt's own, ``_agree_on_port``)."""
-    def make_attempt(k, dp_graph):
-        env = dict(os.environ, MAU_BENCH_WORKER="1", MAU_DP_GRAPH="1" if dp_graph else "0", MASTER_PORT=str(_agree_on_port(k)))
+    ONE worker -- its rank.  The supervisor of local rank 0 leads (``NodeCoordinator``): it picks each attempt and its
+    rendezvous port (rank 0 of the workers hosts a store there -- a port of the attempt's own), the others follow; a failed
+    worker on ANY rank ends the attempt on every rank at once.  One node only: the coordination is through the node's /tmp."""
+    if int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])) != int(os.environ["WORLD_SIZE"]):
+        raise SystemExit("bench.py: the supervised N > 1 run is for ONE node (--nnodes=1): its rank supervisors agree through the node's /tmp")
+    coord = NodeCoordinator()
+
+    def make_attempt(k, dp_graph, port):
+        env = dict(os.environ, MAU_BENCH_WORKER="1", MAU_DP_GRAPH="1" if dp_graph else "0", MASTER_PORT=str(port))
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         # (MAU_BENCH_WORKER_SCRIPT: the CPU tests put a stand-in for the GPU worker here)
         return [([sys.executable, os.environ.get("MAU_BENCH_WORKER_SCRIPT") or os.path.abspath(__file__)] + argv, env)]
 
-    raise SystemExit(run_supervised(make_attempt))
+    raise SystemExit(run_supervised(make_attempt, coord=coord))
 
 
 def workload_key(args):
@@ -521,11 +647,14 @@ def main():
         barrier()
         return time.perf_counter() - t0
 
+    instrumented_region = None
+    if timer.enabled:                # per-launch events inside a region make it slower: that region is measured, but not reported
+        instrumented_region = timed_region()
+        timer.enabled = False
     regions = [timed_region()]
     repeats = args.repeats
     if repeats <= 0:      # ~10 s of contiguous GPU work, the same count on every rank (derived from the max-over-ranks first region)
         repeats = max(1, min(100, int(10.0 / max(1e-3, max_over_ranks(regions)[0]) + 0.5)))
-    timer.enabled = False                                    # (events of the first region only)
     for _ in range(repeats - 1):
         regions.append(timed_region())
     regions = max_over_ranks(regions)                        # per region: the slowest rank's clock
@@ -543,7 +672,139 @@ def main():
         barrier()
         readback_ms = max_over_ranks([time.perf_counter() - t0])[0] / args.steps * 1e3
     stage("timed")
-    timing_pass = "HIP events on the launch stream around every launch, inside the timed region"
+
+    def finish():
+        if world > 1:
+            dist.barrier()                 # every rank is through its work: from here on an exit code cannot cost the measurement
+        stage("done")
+        if world > 1:
+            from mau_amd.dist import destroy_comms
+            destroy_comms()                # the directly-driven RCCL communicators go before the group they were built over
+            dist.destroy_process_group()
+
+    wkey = workload_key(args)
+    peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same rate
+
+    def pmc_record():
+        """PMC counters cannot be read inside this process: HBM traffic, the MFMA-busy fraction and the clock of the dominant
+        kernel come from the separate rocprofv3 --pmc passes of THIS workload committed under profiles/ (scripts/profile.sh +
+        scripts/summarize_profile.py).  The counters describe the LIBRARY they were measured on: the summary carries the sha256
+        of libmau_hip.so, and figures of another binary are not quoted (traffic: null + the reason) -- a kernel change without a
+        re-profile cannot go stale silently."""
+        if args.traffic_bytes is not None:
+            return args.traffic_bytes, "--traffic-bytes", {}
+        import hashlib
+        from mau_amd import _lib
+        with open(_lib.LIB_PATH, "rb") as f:
+            lib_sha = hashlib.sha256(f.read()).hexdigest()
+        src = "no PMC record of this workload under profiles/"
+        for rnd in ("r5", "r4", "r3", "r2"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
+                    cand = json.load(f)[wkey]
+            except (OSError, KeyError, ValueError):
+                continue
+            if cand.get("lib_sha256") != lib_sha:
+                src = (f"profiles/{rnd}/pmc_summary.json[{wkey}] was measured on another build of libmau_hip.so "
+                       f"(sha256 {str(cand.get('lib_sha256'))[:12]} vs loaded {lib_sha[:12]}): not quoted; re-run scripts/profile.sh")
+                break
+            return cand["hbm_bytes_per_launch"], (f"profiles/{rnd}/pmc_summary.json[{wkey}] (same libmau_hip.so, sha256 {lib_sha[:12]}): "
+                                                  "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes"), cand
+        return None, src, {}
+
+    def live_roofline(conv, wg, timing_pass):
+        traffic, traffic_src, rec = pmc_record()
+        achieved = conv["total_flop"] / (conv["total_ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": "conv3x3_bf16_kernel (forward + data-gradient launches)",
+                    "launches": conv["launches"], "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
+                    "flop_per_launch_avg": conv["total_flop"] / conv["launches"],
+                    "share_of_step_time": round(conv["total_ms"] / args.steps / (elapsed / args.steps * 1e3), 4),
+                    "timing": timing_pass,
+                    # PMC figures of the >= 0.3 ms dispatches only (GRBM_GUI_ACTIVE reads high on shorter ones): frac ~ busy x clock / 2.4 GHz
+                    "mfma_busy": rec.get("mfma_busy_long"), "clock_ghz": rec.get("clock_ghz_long"),
+                    "frac_executed_long_dispatches_pmc": rec.get("frac_long"),
+                    "frac_long_launches_live": round(conv["long_tflops"] / peak, 4) if conv.get("long_tflops") else None,
+                    "hbm_gbps": round(traffic / (conv["total_ms"] * 1e-3 / conv["launches"]) / 1e9, 1) if traffic else None}
+        if wg is not None:
+            wach = wg["total_flop"] / (wg["total_ms"] * 1e-3) / 1e12
+            wrec = rec.get("wgrad", {})
+            wflop = wg["total_flop"] / wg["launches"]
+            roofline["wgrad"] = {"kernel": "wgrad16_kernel (+ wgrad_bf16_kernel on small images)", "achieved": round(wach, 2), "frac": round(wach / peak, 4),
+                                 "launches": wg["launches"], "avg_launch_ms": round(wg["total_ms"] / wg["launches"], 4),
+                                 "traffic": wrec.get("hbm_bytes_per_launch_pmc"), "algorithmic_bytes": round(timer.wbytes / wg["launches"]),
+                                 "traffic_ratio": round(wrec["hbm_bytes_per_launch_pmc"] / (timer.wbytes / wg["launches"]), 3) if wrec.get("hbm_bytes_per_launch_pmc") else None,
+                                 "mfma_busy": wrec.get("mfma_busy_long"), "clock_ghz": wrec.get("clock_ghz_long"), "flop_per_launch_avg": wflop,
+                                 # the second stage (mau_conv3x3_unpack_wgrad: fixed-order split-K sum + un-tiling into the gradient arena) counted in
+                                 "unpack_ms_per_step": round(wg.get("unpack_ms", 0.0) / args.steps, 4),
+                                 "frac_with_unpack": round(wg["total_flop"] / ((wg["total_ms"] + wg.get("unpack_ms", 0.0)) * 1e-3) / 1e12 / peak, 4)}
+        return roofline
+
+    def recorded_roofline():
+        """N > 1, before this run's own per-kernel event pass has completed: the dominant kernel's figures of the committed
+        one-GPU record of the same workload (the kernel does not know how many ranks there are) -- replaced by the live
+        figures in the final line; this one only survives if the event pass hangs."""
+        for rnd in ("r5", "r4"):
+            for name in ("bench_default.json", f"bench_{wkey}.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
+                        rec = json.load(f)
+                except (OSError, ValueError):
+                    continue
+                rl = rec.get("roofline")
+                if rl and rec.get("dtype") == args.precision and str(rec.get("config", {}).get("workload", "")).startswith(f"metadata-{args.model_type} "):
+                    rl = dict(rl)
+                    rl["timing"] = (f"NOT of this run: the one-GPU record profiles/{rnd}/{name} (this run's own per-kernel event pass follows the "
+                                    "timed regions and had not completed when this line was printed)")
+                    return rl
+        return {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "timing": "this run's per-kernel event pass had not completed when this line was printed, and no one-GPU record of the workload is committed"}
+
+    def result_line(roofline, fwd):
+        result = {
+            "metric": ("inference images/sec" if args.infer else "train images/sec") + f" ({S}x{S}x{args.channels}->2 {'U-Net' if args.model_type == 'unet' else 'U-Net++'}, B={B}/GPU)",
+            "value": round(B * world * args.steps / elapsed, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "timed_regions": {"repeats": len(regions), "reported": "value / ms_per_step = the MEDIAN region (each region: exactly K steps between barrier + synchronize, max over ranks)",
+                              "ms_per_step_min": round(min(regions) / args.steps * 1e3, 3), "ms_per_step_max": round(max(regions) / args.steps * 1e3, 3),
+                              "ms_per_step_first": round(regions[0] / args.steps * 1e3, 3),
+                              "instrumented_region_excluded": bool(instrumented_region)},
+            "ms_per_step_with_loss_readback": None if readback_ms is None else round(readback_ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": (f"metadata-{args.model_type} base_filters=64, {B}x{args.channels}x{S}x{S} tiles + {args.meta}-dim metadata per GPU, "
+                                    + (f"temperature series of {args.seq_len} months, " if (args.seq_len != 10 or args.temporal_embeddings) else "")
+                                    + ("eval-mode forward only (inference)" if args.infer else "fwd+MSE+bwd+AdamW (src/train.py:243-256)")),
+                       "global_batch": B * world, "parallelism": f"dp{world}" + (" (data-parallel path forced under a 1-rank RCCL group)" if args.force_dist and world == 1 else ""),
+                       "sync_bn": bool(sync is not None and not args.no_sync_bn),
+                       "collectives": (None if sync is None else "RCCL called directly (ncclAllReduce on the compute / communication stream)"
+                                       if sync.comm is not None else f"torch.distributed ({dist.get_backend()})"),
+                       "launch": ("hipGraph replay of the captured step" if graphed is not None else
+                                  "hipGraph replay (GraphedInference session: input copies + replay + output clone per call)" if session[0] is not None
+                                  else "eager (kernel by kernel)")},
+            "rccl_ranks": rccl_ranks,
+            "final_loss": float(losses[-1]),
+            "roofline": roofline,
+        }
+        result.update(fwd)
+        if cpu_rec is not None:
+            result["cpu_baseline"] = cpu_rec
+        return json.dumps(result)
+
+    if world > 1 and rank == 0:
+        # The measurement is in hand: print it NOW.  What follows (the event pass runs the collectives again) can only lose it;
+        # the supervisor forwards the LAST line this worker printed, so the complete line below replaces this one.
+        print(result_line(recorded_roofline(), {"fwd_ms_per_tile": None}), flush=True)
+
+    timing_pass = "HIP events on the launch stream around every launch, inside an instrumented region of its own (not among the reported ones)"
     if separate_pass:
         # the same K steps launched eagerly (kernel by kernel, same resident batch, same kernels, ONE stream) right after the timed
         # region, with the event brackets, for the per-kernel durations
@@ -570,120 +831,36 @@ def main():
         timing_pass = (f"HIP events on the launch stream around every launch over {args.steps} eager steps of the same workload run "
                        "on one stream right after the timed region (the timed steps are hipGraph replays / run the weight gradients on a second stream)")
 
-    # ---- forward latency per tile (eval mode, no_grad), outside the timed region -----------------
-    net.eval()
-    with torch.no_grad():
+    # ---- forward latency per tile (eval mode, no_grad), outside the timed region: what the app calls per click
+    # (app/model_utils.py:102-109) = a frozen inference session replayed as one hipGraph; the eager un-frozen forward beside it ----
+    def per_tile(fn, nf=5):
         for _ in range(2):
-            net(x, ts, md)
+            fn()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        nf = 5
         for _ in range(nf):
-            net(x, ts, md)
+            fn()
         torch.cuda.synchronize()
-        fwd_ms_per_tile = (time.perf_counter() - t1) / nf / B * 1e3
-    net.train()
+        return (time.perf_counter() - t1) / nf / B * 1e3
 
-    def finish():
-        if world > 1:
-            dist.barrier()                 # every rank is through its work: from here on an exit code cannot cost the measurement
-        stage("done")
-        if world > 1:
-            dist.destroy_process_group()
+    net.eval()
+    with torch.no_grad():
+        fwd_eager = per_tile(lambda: net(x, ts, md))
+    fwd = {"fwd_ms_per_tile": round(fwd_eager, 4), "fwd_ms_per_tile_eager_unfrozen": round(fwd_eager, 4), "fwd_ms_per_tile_path": "eager eval forward (no inference session)"}
+    if not args.infer and world == 1:
+        sess = mau_amd.GraphedInference(net, x, ts, md)             # (freezes the model; net.train() below unfreezes it)
+        fwd["fwd_ms_per_tile"] = round(per_tile(lambda: sess(x, ts, md)), 4)
+        fwd["fwd_ms_per_tile_path"] = f"freeze_inference + GraphedInference replay at B={B} (the product's inference path)"
+        del sess
+    elif session[0] is not None:
+        fwd["fwd_ms_per_tile"] = round(per_tile(lambda: session[0](x, ts, md)), 4)
+        fwd["fwd_ms_per_tile_path"] = f"freeze_inference + GraphedInference replay at B={B} (the product's inference path)"
+    net.train()
 
     if rank != 0:
         return finish()
 
-    conv = timer.summary()
-    wg = timer.wgrad_summary()
-    # PMC counters cannot be read inside this process: HBM traffic, the MFMA-busy fraction and the clock of the dominant kernel come
-    # from the separate rocprofv3 --pmc passes of THIS workload committed under profiles/ (scripts/profile.sh + scripts/summarize_profile.py)
-    wkey = workload_key(args)
-    traffic, traffic_src, rec = args.traffic_bytes, "--traffic-bytes", {}
-    if traffic is None:
-        # The counters describe the LIBRARY they were measured on: the summary carries the sha256 of libmau_hip.so, and figures of
-        # another binary are not quoted (traffic: null + the reason) -- a kernel change without a re-profile cannot go stale silently.
-        import hashlib
-        from mau_amd import _lib
-        with open(_lib.LIB_PATH, "rb") as f:
-            lib_sha = hashlib.sha256(f.read()).hexdigest()
-        traffic_src = "no PMC record of this workload under profiles/"
-        for rnd in ("r4", "r3", "r2"):
-            try:
-                with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
-                    cand = json.load(f)[wkey]
-            except (OSError, KeyError, ValueError):
-                continue
-            if cand.get("lib_sha256") != lib_sha:
-                traffic_src = (f"profiles/{rnd}/pmc_summary.json[{wkey}] was measured on another build of libmau_hip.so "
-                               f"(sha256 {str(cand.get('lib_sha256'))[:12]} vs loaded {lib_sha[:12]}): not quoted; re-run scripts/profile.sh")
-                break
-            rec = cand
-            traffic = rec["hbm_bytes_per_launch"]
-            traffic_src = (f"profiles/{rnd}/pmc_summary.json[{wkey}] (same libmau_hip.so, sha256 {lib_sha[:12]}): "
-                           "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate rocprofv3 --pmc passes")
-            break
-    peak = PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS      # fp16 and bf16 MFMA run at the same rate
-    achieved = conv["total_flop"] / (conv["total_ms"] * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "conv3x3_bf16_kernel (forward + data-gradient launches)",
-                "launches": conv["launches"], "avg_launch_ms": round(conv["total_ms"] / conv["launches"], 4),
-                "flop_per_launch_avg": conv["total_flop"] / conv["launches"],
-                "share_of_step_time": round(conv["total_ms"] / args.steps / (elapsed / args.steps * 1e3), 4),
-                "timing": timing_pass,
-                # PMC figures of the >= 0.3 ms dispatches only (GRBM_GUI_ACTIVE reads high on shorter ones): frac ~ busy x clock / 2.4 GHz
-                "mfma_busy": rec.get("mfma_busy_long"), "clock_ghz": rec.get("clock_ghz_long"),
-                "frac_executed_long_dispatches_pmc": rec.get("frac_long"),
-                "frac_long_launches_live": round(conv["long_tflops"] / peak, 4) if conv.get("long_tflops") else None,
-                "hbm_gbps": round(traffic / (conv["total_ms"] * 1e-3 / conv["launches"]) / 1e9, 1) if traffic else None}
-    if wg is not None:
-        wach = wg["total_flop"] / (wg["total_ms"] * 1e-3) / 1e12
-        wrec = rec.get("wgrad", {})
-        wflop = wg["total_flop"] / wg["launches"]
-        roofline["wgrad"] = {"kernel": "wgrad16_kernel (+ wgrad_bf16_kernel on small images)", "achieved": round(wach, 2), "frac": round(wach / peak, 4),
-                             "launches": wg["launches"], "avg_launch_ms": round(wg["total_ms"] / wg["launches"], 4),
-                             "traffic": wrec.get("hbm_bytes_per_launch_pmc"), "algorithmic_bytes": round(timer.wbytes / wg["launches"]),
-                             "traffic_ratio": round(wrec["hbm_bytes_per_launch_pmc"] / (timer.wbytes / wg["launches"]), 3) if wrec.get("hbm_bytes_per_launch_pmc") else None,
-                             "mfma_busy": wrec.get("mfma_busy_long"), "clock_ghz": wrec.get("clock_ghz_long"), "flop_per_launch_avg": wflop,
-                             # the second stage (mau_conv3x3_unpack_wgrad: fixed-order split-K sum + un-tiling into the gradient arena) counted in
-                             "unpack_ms_per_step": round(wg.get("unpack_ms", 0.0) / args.steps, 4),
-                             "frac_with_unpack": round(wg["total_flop"] / ((wg["total_ms"] + wg.get("unpack_ms", 0.0)) * 1e-3) / 1e12 / peak, 4)}
-    result = {
-        "metric": ("inference images/sec" if args.infer else "train images/sec") + f" ({S}x{S}x{args.channels}->2 {'U-Net' if args.model_type == 'unet' else 'U-Net++'}, B={B}/GPU)",
-        "value": round(B * world * args.steps / elapsed, 2),
-        "unit": "images/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "timed_regions": {"repeats": len(regions), "reported": "median region (each region: exactly K steps between barrier + synchronize, max over ranks)",
-                          "ms_per_step_min": round(min(regions) / args.steps * 1e3, 3), "ms_per_step_max": round(max(regions) / args.steps * 1e3, 3),
-                          "ms_per_step_first": round(regions[0] / args.steps * 1e3, 3)},
-        "ms_per_step_with_loss_readback": None if readback_ms is None else round(readback_ms, 3),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": args.precision,
-        "data": "synthetic",
-        "config": {"workload": (f"metadata-{args.model_type} base_filters=64, {B}x{args.channels}x{S}x{S} tiles + {args.meta}-dim metadata per GPU, "
-                                + (f"temperature series of {args.seq_len} months, " if (args.seq_len != 10 or args.temporal_embeddings) else "")
-                                + ("eval-mode forward only (inference)" if args.infer else "fwd+MSE+bwd+AdamW (src/train.py:243-256)")),
-                   "global_batch": B * world, "parallelism": f"dp{world}" + (" (data-parallel path forced under a 1-rank RCCL group)" if args.force_dist and world == 1 else ""),
-                   "sync_bn": bool(sync is not None and not args.no_sync_bn),
-                   "collectives": (None if sync is None else "RCCL called directly (ncclAllReduce on the compute / communication stream)"
-                                   if sync.comm is not None else f"torch.distributed ({dist.get_backend()})"),
-                   "launch": ("hipGraph replay of the captured step" if graphed is not None else
-                              "hipGraph replay (GraphedInference session: input copies + replay + output clone per call)" if session[0] is not None
-                              else "eager (kernel by kernel)")},
-        "rccl_ranks": rccl_ranks,
-        "fwd_ms_per_tile": round(fwd_ms_per_tile, 4),
-        "final_loss": float(losses[-1]),
-        "roofline": roofline,
-    }
-    if cpu_rec is not None:
-        result["cpu_baseline"] = cpu_rec
-    print(json.dumps(result), flush=True)
+    print(result_line(live_roofline(timer.summary(), timer.wgrad_summary(), timing_pass), fwd), flush=True)
     finish()
 
 

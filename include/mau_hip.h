@@ -45,11 +45,22 @@ extern "C" {
 typedef void* mau_stream_t;
 
 /* ---- library ---------------------------------------------------------- */
-#define MAU_ABI_VERSION 3  /* 2: single-launch reductions (tickets), multi-tensor weight pack, fused BatchNorm passes; 3: first-layer kernels */
+#define MAU_ABI_VERSION 4  /* 2: single-launch reductions (tickets), multi-tensor weight pack, fused BatchNorm passes; 3: first-layer kernels; 4: mau_set_cu_budget */
 int mau_abi_version(void);
 const char* mau_last_error(void);
 /* 0 when the current HIP device is a gfx950 (MI355X); MAU_ERR_DEVICE otherwise. */
 int mau_device_check(void);
+
+/* Compute-unit budget of the CALLING THREAD's later launches (0 = the whole device; returns the previous value).  The backward
+ * pass of src/train.py:252 has two independent chains once a layer's dy exists -- the data gradients with the BatchNorm passes
+ * between them, and the weight gradients -- and every convolution / weight-gradient launch is sized to occupy all compute
+ * units (persistent grid, LDS and registers full), so two of them on two streams take turns.  With a budget the 3x3 convolution
+ * launches (mau_conv3x3_fwd*, 16-bit) use a persistent grid of `cus` workgroup slots and the weight gradient
+ * (mau_conv3x3_wgrad*, mau_conv3x3_wgrad_splits / _acc_elems) picks its split-K count for `cus` workgroups: chains launched
+ * with budgets b and total - b run side by side.  Rounded down to a whole number of CUs per XCD.  Results of the convolution
+ * do not depend on it; the weight gradient's fixed-order split-K sum is a different (still deterministic) partition, so call
+ * _splits / _acc_elems / _wgrad* / _unpack_wgrad of one layer under ONE budget. */
+int mau_set_cu_budget(int cus);
 
 /* ---- layout at the module boundary ------------------------------------ */
 /* maps (B,C,H,W) fp32 as handed over by collate_fn (src/dataset.py:99-106) -> NHWC-ld. */

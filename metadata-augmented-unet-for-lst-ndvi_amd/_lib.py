@@ -28,6 +28,7 @@ PROTOTYPES = {
     "mau_abi_version": (_i, []),
     "mau_last_error": (C.c_char_p, []),
     "mau_device_check": (_i, []),
+    "mau_set_cu_budget": (_i, [_i]),
     "mau_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_pack_tile_onehot": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mau_flip_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

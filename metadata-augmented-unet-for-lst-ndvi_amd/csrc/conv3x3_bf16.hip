@@ -961,7 +961,8 @@ static int launch(const ConvP& p, hipStream_t st) {
   const int nItems = round_up(nPixTiles, xcds) * nCt;
   // persistent: as many workgroups as fit the chip at once
   const int per_cu = (int)((160 * 1024) / G::LDS) >= 2 && NW == 4 ? 2 : 1;
-  int grid = ds.cus / ds.xcds * ds.xcds * per_cu;      // a multiple of the XCD count, like nItems: a workgroup stays on its XCD's slice
+  // (launch_cus(): the device's CUs, or the calling thread's budget -- mau_set_cu_budget)
+  int grid = launch_cus() / ds.xcds * ds.xcds * per_cu;      // a multiple of the XCD count, like nItems: a workgroup stays on its XCD's slice
   if (grid > nItems) grid = nItems;
   // the 16x16x32 loop walks stages in pairs: big-tile variants, buffer-addressed loader, an even number of stages
   // (MAU_CONV_M16=0: the 32x32x16 loop everywhere, for same-box A/B timing)

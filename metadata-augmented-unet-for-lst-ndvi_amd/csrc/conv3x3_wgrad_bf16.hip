@@ -412,7 +412,7 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   if ((size_t)smax > cap) smax = (int)cap;
   int best = 1;
   double best_score = -1.0;
-  const long cus = device_shape().cus;
+  const long cus = launch_cus();                    // the device's CUs, or the calling thread's budget (mau_set_cu_budget)
   const int xcds = wg2::wgrad_xcd_order() ? device_shape().xcds : 1;
   for (int s = 1; s <= smax; ++s) {                // s = workgroups along the split axis = partial slabs
     if (s >= xcds && s % xcds != 0) continue;      // whole splits per XCD (see the kernel's work-item order)

@@ -130,23 +130,86 @@ class RcclComm:
     def destroy(self):
         self._fin()
 
+    def abort(self):
+        """``ncclCommAbort``: ends a collective that will never complete (a dead or mis-ordered peer) so that the process can
+        leave; the communicator is unusable afterwards."""
+        if self._fin.detach() is not None:
+            try:
+                _rccl().ncclCommAbort(self._comm)
+            except Exception:
+                pass
 
+
+# (id(group), tag, device) -> (group, communicator).  The entry holds the group OBJECT: while it is here CPython cannot hand its
+# id to another group, and a lookup checks identity -- a communicator built over a destroyed group is never returned for a new one.
 _COMMS = {}
 
 
-def rccl_comm(group, tag: str) -> Optional[RcclComm]:
+def direct_rccl(direct: Optional[bool] = None) -> bool:
+    """Whether the data-path collectives are issued as direct RCCL calls: the caller's explicit choice, else ``MAU_RCCL_DIRECT``
+    (1 / 0), else yes."""
+    if direct is not None:
+        return bool(direct)
+    return os.environ.get("MAU_RCCL_DIRECT", "1") != "0"
+
+
+def rccl_comm(group, tag: str, direct: Optional[bool] = None) -> Optional[RcclComm]:
     """The process's communicator ``tag`` ("bn" / "grad") over ``group``, created on first use by EVERY rank of the group
-    (creation is itself a collective); ``None`` when the group does not run on RCCL (gloo rehearsals, CPU tests) or
-    ``MAU_RCCL_DIRECT=0`` (A/B switch: everything through ProcessGroupNCCL, as in round 3)."""
+    (creation is itself a collective); ``None`` when the group does not run on RCCL (gloo rehearsals, CPU tests) or the direct
+    path is off (``direct=False`` / ``MAU_RCCL_DIRECT=0``: everything through ProcessGroupNCCL, as in round 3)."""
     if group is None or not torch.cuda.is_available() or dist.get_backend(group) != "nccl":
         return None
-    if os.environ.get("MAU_RCCL_DIRECT", "1") == "0":
+    if not direct_rccl(direct):
         return None
     key = (id(group), tag, torch.cuda.current_device())
-    c = _COMMS.get(key)
-    if c is None:
-        c = _COMMS[key] = RcclComm(group)
-    return c
+    ent = _COMMS.get(key)
+    if ent is None or ent[0] is not group:
+        ent = _COMMS[key] = (group, RcclComm(group))
+    return ent[1]
+
+
+def destroy_comms(abort: bool = False):
+    """Destroy (or abort) every directly-driven communicator of the process and forget them.  Call it BEFORE
+    ``dist.destroy_process_group()``: the communicators were built over the group's ranks and must not outlive it."""
+    for _, c in list(_COMMS.values()):
+        c.abort() if abort else c.destroy()
+    _COMMS.clear()
+
+
+class CollectiveWatchdog:
+    """A directly-issued ``ncclAllReduce`` has no timeout of its own (ProcessGroupNCCL's watchdog never sees it): a peer that
+    died, or two communicators' kernels started in different orders on two ranks, is a silent hang.  The training loop calls
+    ``kick()`` once per finished step (after a host read-back, so "finished" means the GPU was there); when no kick arrives for
+    ``timeout_s`` the watchdog thread says so, aborts the communicators (``ncclCommAbort``) and ends the process with a
+    non-zero code -- the launcher then ends the other ranks."""
+
+    def __init__(self, timeout_s: Optional[float] = None, exit_code: int = 86, _exit=os._exit):
+        import threading
+        import time
+        self.timeout_s = float(os.environ.get("MAU_DIST_TIMEOUT_S", "600")) if timeout_s is None else float(timeout_s)
+        self._exit, self._code, self._time = _exit, exit_code, time
+        self._last = time.monotonic()
+        self._stop = threading.Event()
+        self.fired = False
+        self._thread = threading.Thread(target=self._watch, daemon=True, name="mau-collective-watchdog")
+        self._thread.start()
+
+    def kick(self):
+        self._last = self._time.monotonic()
+
+    def _watch(self):
+        while not self._stop.wait(min(1.0, self.timeout_s / 4)):
+            if self._time.monotonic() - self._last > self.timeout_s:
+                import sys
+                self.fired = True
+                print(f"mau_amd.dist: no training step finished for {self.timeout_s:.0f} s -- a collective is hung; aborting the RCCL "
+                      f"communicators and leaving with code {self._code}", file=sys.stderr, flush=True)
+                destroy_comms(abort=True)
+                self._exit(self._code)
+                return
+
+    def close(self):
+        self._stop.set()
 
 
 def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
@@ -181,7 +244,7 @@ class GradSync:
         sync.begin(); loss.backward(); sync.finish(); optimizer.step(); optimizer.zero_grad()
     """
 
-    def __init__(self, module: torch.nn.Module, group=None, bucket_bytes: int = 32 << 20):
+    def __init__(self, module: torch.nn.Module, group=None, bucket_bytes: int = 32 << 20, direct: Optional[bool] = None):
         self.group = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
         self.world = dist.get_world_size(self.group) if self.group is not None else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -216,7 +279,7 @@ class GradSync:
         self._active = False
         self._avg = self.group is not None and dist.get_backend(self.group) == "nccl"
         # RCCL called directly on a communication stream of our own (module docstring); None = through torch.distributed
-        self.comm = rccl_comm(self.group, "grad") if dev.type == "cuda" else None
+        self.comm = rccl_comm(self.group, "grad", direct) if dev.type == "cuda" else None
         self.comm_stream = torch.cuda.Stream(device=dev) if self.comm is not None else None
         self._comm_used = False
         self._dirty = set()           # ids of parameters whose arena slot has held a gradient (the arena starts zeroed)

@@ -246,9 +246,10 @@ class _NetBase(nn.Module):
         self.freeze_inference(False)
         return super().load_state_dict(*args, **kwargs)
 
-    def set_sync_bn(self, group=None, world_size: Optional[int] = None):
+    def set_sync_bn(self, group=None, world_size: Optional[int] = None, direct: Optional[bool] = None):
         """All-reduce BatchNorm batch statistics over ``group`` (RCCL); ``None``/world 1 = local BN.
-        Collective: every rank of the group must call it (it creates the group's SyncBN communicator, ``dist.rccl_comm``)."""
+        Collective: every rank of the group must call it (it creates the group's SyncBN communicator, ``dist.rccl_comm``).
+        ``direct``: RCCL called directly on the compute stream (None = ``MAU_RCCL_DIRECT``, default on) or ProcessGroupNCCL."""
         import torch.distributed as dist
         if group is None and not (dist.is_available() and dist.is_initialized()):
             self._rt.group, self._rt.world, self._rt.comm = None, 1, None
@@ -258,7 +259,7 @@ class _NetBase(nn.Module):
         self._rt.group = g
         self._rt.world = world_size if world_size is not None else dist.get_world_size(g)
         on_gpu = next(self.parameters()).is_cuda
-        self._rt.comm = rccl_comm(g, "bn") if on_gpu else None
+        self._rt.comm = rccl_comm(g, "bn", direct) if on_gpu else None
         return self
 
     def _entry(self, maps) -> Act:

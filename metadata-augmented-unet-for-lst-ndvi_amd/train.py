@@ -118,11 +118,19 @@ def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study
         criterion = compute_loss_l1_grad_ssim
     else:
         raise NotImplementedError(f"Loss {cfg.loss} not implemented.")
-    sync = None
+    sync = watchdog = None
     import torch.distributed as dist
     if world > 1 or (force_dist and dist.is_available() and dist.is_initialized()):
-        model.set_sync_bn(dist.group.WORLD)
-        sync = GradSync(model)
+        # Collectives: RCCL called directly on our streams (dist.RcclComm) is the measured path of bench.py, where a supervisor
+        # with a fallback stands behind it.  Here nothing does, and two communicators driven from two streams have not yet
+        # run between two GPUs: between REAL ranks the training driver goes through ProcessGroupNCCL (its own watchdog, its own
+        # timeout) unless MAU_RCCL_DIRECT=1 asks for the direct path -- which then runs under a watchdog of ours.
+        direct = (os.environ["MAU_RCCL_DIRECT"] != "0") if "MAU_RCCL_DIRECT" in os.environ else (world == 1)
+        model.set_sync_bn(dist.group.WORLD, direct=direct)
+        sync = GradSync(model, direct=direct)
+        if sync.comm is not None and world > 1:
+            from .dist import CollectiveWatchdog
+            watchdog = CollectiveWatchdog()
     hyper = build_hyperparameters(cfg, model_type, temporal_embeddings, metadata_embeddings,
                                   CONFIG.dataset.input_channels, CONFIG.dataset.target_channels)
     gen = torch.Generator().manual_seed(CONFIG.seed + rank)
@@ -157,10 +165,14 @@ def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study
                 optimizer.step()
                 optimizer.zero_grad()
             total += batch_loss.detach().cpu().item() * len(inputs)                         # src/train.py:258-260
+            if watchdog is not None:
+                watchdog.kick()                                                             # (the read-back above: the step HAS finished)
             num += len(inputs)
             step += 1
         epoch_loss = total / max(num, 1)
         val_loss, _ = validate(model, val_loader, criterion)                                # src/train.py:286
+        if watchdog is not None:
+            watchdog.kick()
         history.append((epoch_loss, val_loss))
         if rank == 0:
             typer.echo(f"Epoch {epoch + 1} | step {step} | Train Loss: {epoch_loss:.6f} | Val Loss: {val_loss:.6f}")
@@ -171,6 +183,8 @@ def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study
                 save_checkpoint(ckpt_path, model, optimizer, epoch=epoch, step=step, loss=best,
                                 hyperparameters=hyper, model_type=model_type, study_name=study_name, trial_id=0,
                                 metadata_input_length=n_meta)
+    if watchdog is not None:
+        watchdog.close()
     return {"best": best, "model": model, "optimizer": optimizer, "checkpoint_path": ckpt_path, "history": history}
 
 

@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libmau_hip.so does not export {s}"
     assert sorted(_lib.PROTOTYPES) == syms, (set(_lib.PROTOTYPES) ^ set(syms))
-    assert _lib.lib.mau_abi_version() == 3
+    assert _lib.lib.mau_abi_version() == 4
     # pure host-side helpers of the ABI are callable without a GPU
     assert _lib.lib.mau_conv3x3_kc(_lib.MAU_BF16) == 16 and _lib.lib.mau_conv3x3_kc(_lib.MAU_F32) == 16
     assert _lib.lib.mau_conv3x3_packed_elems(_lib.MAU_BF16, 64, 6) == 1 * 9 * 64 * 16

@@ -117,3 +117,73 @@ def test_syncbn_exchange_world2_equals_reference_single_device(tmp_path):
     for p in parts:                                          # running stats identical on every rank == reference's
         assert rel_err(p["rm"], sd1["bn1.running_mean"]) < 1e-5
         assert rel_err(p["rv"], sd1["bn1.running_var"]) < 1e-5
+
+
+def test_comm_cache_is_keyed_on_the_group_object_and_destroy_comms_clears_it(monkeypatch):
+    """``_COMMS`` was keyed by ``id(group)`` alone -- after destroy_process_group() CPython may hand the id to a NEW
+    group and the stale communicator came back.  The entry now holds the group object and a lookup checks identity."""
+    from mau_amd import dist as D
+
+    class FakeComm:
+        made = 0
+
+        def __init__(self, group):
+            FakeComm.made += 1
+            self.group, self.destroyed, self.aborted = group, False, False
+
+        def destroy(self):
+            self.destroyed = True
+
+        def abort(self):
+            self.aborted = True
+
+    monkeypatch.setattr(D, "RcclComm", FakeComm)
+    monkeypatch.setattr(D.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(D.torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(D.dist, "get_backend", lambda g=None: "nccl")
+    monkeypatch.delenv("MAU_RCCL_DIRECT", raising=False)
+    D._COMMS.clear()
+    g1, g2 = object(), object()
+    c1 = D.rccl_comm(g1, "bn")
+    assert D.rccl_comm(g1, "bn") is c1 and D.rccl_comm(g1, "grad") is not c1 and FakeComm.made == 2
+    # a different group object that lands on the same key (what id reuse after a destroyed group looks like) gets its OWN communicator
+    key = (id(g1), "bn", 0)
+    D._COMMS[(id(g2), "bn", 0)] = D._COMMS[key]                      # a stale entry sitting under g2's id
+    c2 = D.rccl_comm(g2, "bn")
+    assert c2 is not c1 and c2.group is g2
+    # explicit choice beats the environment, the environment beats the default
+    assert D.rccl_comm(g1, "x", direct=False) is None
+    monkeypatch.setenv("MAU_RCCL_DIRECT", "0")
+    assert D.rccl_comm(g1, "bn") is None and D.rccl_comm(g1, "bn", direct=True) is c1
+    comms = [c for _, c in D._COMMS.values()]
+    D.destroy_comms()
+    assert not D._COMMS and all(c.destroyed for c in comms)
+    monkeypatch.delenv("MAU_RCCL_DIRECT")
+    c3 = D.rccl_comm(g1, "bn")
+    D.destroy_comms(abort=True)
+    assert c3.aborted and not D._COMMS
+
+
+def test_collective_watchdog_aborts_and_exits_when_no_step_finishes():
+    """A directly-issued ncclAllReduce has no timeout: the training driver's watchdog turns a hung collective into
+    ncclCommAbort + a non-zero exit."""
+    import time
+    from mau_amd import dist as D
+
+    class FakeComm:
+        aborted = False
+
+        def abort(self):
+            FakeComm.aborted = True
+
+    D._COMMS.clear()
+    D._COMMS[(1, "grad", 0)] = (object(), FakeComm())
+    codes = []
+    wd = D.CollectiveWatchdog(timeout_s=0.4, _exit=codes.append)
+    for _ in range(4):                                               # steps keep finishing: nothing happens
+        time.sleep(0.2)
+        wd.kick()
+    assert not wd.fired and not codes
+    time.sleep(1.2)                                                  # ... then one never does
+    assert wd.fired and codes == [86] and FakeComm.aborted and not D._COMMS
+    wd.close()
