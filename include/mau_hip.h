@@ -105,6 +105,11 @@ int mau_conv3x3_pack_weights_multi(const void* descs, int n, int total_tiles, in
  * channels: one per 8x16-pixel tile for MAU_F32; one per (workgroup tile of 16x16 or 32x16 pixels, wave row) for
  * MAU_BF16 -- the tile height is chosen per layer from how well its work items fill the 256 CUs. */
 int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout);
+/* Which tile variant of the convolution kernel runs such a layer (diagnostics and tests: "did the big-tile variant run?"):
+ * pixel rows of a workgroup tile (16 pixels wide), waves per workgroup, output channels per workgroup -- written to HOST ints.
+ * 16-bit: (64,8,64) = <64,4,8>, (32,4,64) = <64,4,4> (two workgroups per CU, level 0), (32,8,128) = <128,4,8>, (16,..) / (8,..) =
+ * the small-image forms; MAU_F32: the fp32 kernel's one tiling. */
+int mau_conv3x3_variant(int dtype, int N, int H, int W, int Cout, int* tile_rows_host, int* waves_host, int* cout_block_host);
 /* The network's FIRST convolution (reference src/model.py:222 / :67 conv0_0.conv1; nn.Conv2d(spatial_channels, 64, 3, padding=1),
  * src/model.py:12) for inputs of at most mau_conv3x3_first_max_channels() = 8 channels, 16-bit modes: reads the input AS THE
  * REFERENCE'S collate_fn DELIVERS IT -- x (N,Cin,H,W) fp32 contiguous (src/dataset.py:99-106) -- and the fp32 master weights

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "mau_conv3x3_pack_desc_fill": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_pack_weights_multi": (_i, [_p, _i, _i, _i, _p]),
     "mau_conv3x3_num_pixel_tiles": (_i, [_i, _i, _i, _i, _i]),
+    "mau_conv3x3_variant": (_i, [_i, _i, _i, _i, _i, _p, _p, _p]),
     "mau_conv3x3_first_max_channels": (_i, []),
     "mau_conv3x3_first_rows": (_i, [_i, _i, _i]),
     "mau_conv3x3_first_wgrad_ws_elems": (_sz, [_i, _i, _i, _i]),
@@ -140,6 +141,13 @@ def check(status: int, what: str = ""):
     if status != 0:
         msg = lib.mau_last_error()
         raise MauError(f"libmau_hip {what} failed (status {status}): {msg.decode() if msg else '?'}")
+
+
+def conv3x3_variant(dtype: int, N: int, H: int, W: int, Cout: int):
+    """(tile rows, waves per workgroup, output channels per workgroup) of the convolution variant that runs such a layer."""
+    th, nw, bn = C.c_int(), C.c_int(), C.c_int()
+    check(lib.mau_conv3x3_variant(dtype, N, H, W, Cout, C.byref(th), C.byref(nw), C.byref(bn)), "mau_conv3x3_variant")
+    return th.value, nw.value, bn.value
 
 
 def call(name: str, *args):

@@ -283,18 +283,26 @@ __device__ __forceinline__ void dma_issue_buf(__amdgpu_buffer_rsrc_t rs, int vof
 // ONE: the layer reads ONE tensor (no second source, no broadcast embedding) -- every data gradient and all but five forward launches
 // of a step.  The per-DMA choice of the source then disappears from the multiply loop (it was 38 scalar compare-and-branch pairs per
 // stage pair between the MFMAs: -1.5...3 % of a launch), with it the second source's lane offsets (5 registers).
-template <int BN, int MT, int NW, int EPI, bool F16, bool FAST, bool M16, bool ONE = false>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
+// KG = 2 (K groups): the workgroup is TWO wave groups of NW waves on the SAME work item, group g multiplying the 16-channel stages
+// g, g + 2, ... out of LDS buffers of its own; group 1 hands its accumulators to group 0 through LDS, group 0 runs the epilogue.
+// For under-filled layers (single-tile inference at the deep levels: fewer items than half the CUs, one 4-wave workgroup per CU): a
+// wave's dependent chain of 9 * Cin / 16 MFMA groups halves and every SIMD holds two waves that hide each other's latencies.
+template <int BN, int MT, int NW, int EPI, bool F16, bool FAST, bool M16, bool ONE = false, int KG = 1>
+__global__ __launch_bounds__(NW * KG * 64, 2) void conv3x3_bf16_kernel(ConvP p, int nPixTiles, int nCt, int nItems) {
   static_assert(!M16 || (MT == 4 && (NW == 8 || (NW == 4 && BN == 64)) && FAST), "the 16x16x32 loop: 128-pixel wave strips, buffer-addressed loader");
   static_assert(!ONE || M16, "single-source instantiations exist for the 16x16x32 variants only");
+  static_assert(KG == 1 || (KG == 2 && !M16 && NW == 4 && BN == 64 && FAST && EPI != EPI_STATS), "K groups: the 4-wave 64-channel forms of the 32x32x16 loop");
   using G = Geo<BN, MT, NW>;
   constexpr int WN = G::WN, WM = G::WM, TH = G::TH, HPIX = G::HPIX, HALO_Q = G::HALO_Q, HALO_BYTES = G::HALO_BYTES;
   constexpr int TOT_Q = G::TOT_Q, STAGE = G::STAGE, PER_WAVE = G::PER_WAVE;
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE + red
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];   // KG x (2 * STAGE)
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG == 1 ? 0 : wave_all / NW;          // K group of this wave; `wave` is its index INSIDE the group everywhere below
+  const int wave = KG == 1 ? wave_all : wave_all % NW;
+  unsigned char* const smem = smem_all + kg * (2 * STAGE);
 #ifdef MAU_CONV_SETPRIO      // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for the second-dispatched half
   if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
   int I = next_valid(blockIdx.x, cur);
   if (I < 0) return;                                  // whole workgroup leaves before any barrier
   setup(cur);
-  static_for<0, PER_WAVE>([&](auto jc) { MAU_ISSUE_SLOT(decltype(jc)::value, 0, 0); });
+  static_for<0, PER_WAVE>([&](auto jc) { MAU_ISSUE_SLOT(decltype(jc)::value, 0, kg); });      // (group g starts with stage g)
   int stage = 0;
   unsigned short* __restrict__ yg = reinterpret_cast<unsigned short*>(p.y);
 
@@ -576,11 +584,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
         }
       }
     } else
-    for (int chunk = 0; chunk < p.nChunks; ++chunk) {
+    for (int chunk = kg; chunk < p.nChunks; chunk += KG) {        // (KG = 2: the launcher sends only even stage counts -- same barriers in both groups)
       // next stage: the following chunk of this item, or chunk 0 of the next item (cross-tile pipelining);
       // after the very last stage chunk 0 of the current item is re-fetched into the idle buffer (nobody reads it)
-      const bool more = chunk + 1 < p.nChunks;
-      const int fchunk = more ? chunk + 1 : 0;
+      const bool more = chunk + KG < p.nChunks;
+      const int fchunk = more ? chunk + KG : kg;
       if (!more && In >= 0) setup(nxt);
       // Operand fragments are double-buffered in registers: the ds_reads of tap t+1 are issued BEFORE the
       // MFMAs of tap t, so the only LDS round trip a wave waits out is the first one of a stage (timing
@@ -648,9 +656,49 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
 
     // ---- epilogue of `cur` (the next item's first stage is already in flight into buffer `stage`) ----
     __builtin_amdgcn_s_barrier();                      // every wave is done reading buffer stage^1 -> reuse it
+    const bool full = cur.ty0 + TH <= p.H && cur.tx0 + TW <= p.W;     // interior tiles (the common case): mask-free, workgroup-uniform
+    if constexpr (KG == 2) {
+      // group 1 -> group 0: MT * 32 accumulator registers per wave = MT * 32 KB, through the two groups' idle stage^1 buffers (registers
+      // 4 j .. 4 j + 3 of wave w: the 1 KB block (w * R4 + j) of the area [group 1's buffer | group 0's buffer]); fixed order: group 0 + group 1.
+      constexpr int R4 = MT * 8;
+      static_assert((size_t)NW * R4 * 1024 <= 2 * (size_t)STAGE && STAGE % 1024 == 0, "accumulator hand-over area");
+      const unsigned lds_all = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem_all);
+      const unsigned b1 = lds_all + (2 + (stage ^ 1)) * STAGE, b0 = lds_all + (stage ^ 1) * STAGE;
+      auto slot = [&](int j) -> unsigned {
+        const unsigned o = (unsigned)((wave * R4 + j) * 1024);
+        return (o < (unsigned)STAGE ? b1 + o : b0 + (o - (unsigned)STAGE)) + lane * 16;
+      };
+      if (kg == 1) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+              lds_write_f32x4(slot((a * 2 + b) * 4 + g), v);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (kg == 0) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          f32x4 t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = lds_read_f32x4(slot(a * 8 + j));
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][j >> 2][4 * (j & 3) + e] += t[j][e];
+        }
+      }
+      __builtin_amdgcn_s_barrier();                    // the hand-over area overlaps OTHER waves' epilogue staging rows
+    }
+    if (KG == 1 || kg == 0) {
     // wave-private staging image: 32 pixels x 64 channels bf16 (128-byte rows)
     const unsigned stg = lds0 + (stage ^ 1) * STAGE + wave * (32 * 64 * 2);
-    const bool full = cur.ty0 + TH <= p.H && cur.tx0 + TW <= p.W;     // interior tiles (the common case): mask-free, workgroup-uniform
     const unsigned rbase = stg + (lane >> 3) * 128 + (lane & 7) * 16;   // read: pixel pass*8 + lane/8, 16-byte vector lane%8
     const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
     if constexpr (M16) {
@@ -909,8 +957,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_bf16_kernel(ConvP p, int n
       }
     }
     }   // (!M16)
+    }   // (KG == 1 || kg == 0)
     if (In < 0) break;
-    stores_behind = full && cur.co0 + wn * 64 + 64 <= p.ldy;     // every lane stored, 4 * MT store instructions per wave
+    stores_behind = (KG == 1 || kg == 0) && full && cur.co0 + wn * 64 + 64 <= p.ldy;     // every lane stored, 4 * MT store instructions per wave
     cur = nxt;
     I = In;
   }
@@ -932,6 +981,8 @@ static int launch(const ConvP& p, hipStream_t st) {
     MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>);
     MAU_LDS_ATTR(G::LDS, (&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true, true>));
   }
+  constexpr bool HAS_KG = BN == 64 && NW == 4 && MT <= 2 && EPI != EPI_STATS;       // the under-filled-layer forms <64,1,4> / <64,2,4>
+  if constexpr (HAS_KG) MAU_LDS_ATTR(2 * G::LDS, (&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, false, false, 2>));
   const DeviceShape ds = device_shape();
   const int tilesX = ceil_div(p.W, TW), tilesY = ceil_div(p.H, G::TH);
   ConvP q = p;
@@ -975,6 +1026,16 @@ static int launch(const ConvP& p, hipStream_t st) {
         MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
       else
         MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
+      done = true;
+    }
+  }
+  if constexpr (HAS_KG) {
+    // Two K groups per workgroup where the layer leaves every CU at most ONE 4-wave workgroup (single-tile inference at the deep
+    // levels): the stages are dealt to two wave groups, a wave's chain of dependent MFMA groups halves and each SIMD
+    // holds two waves.  Even stage counts only (same barriers in both groups); MAU_CONV_KG=0 switches it off (A/B).
+    static const bool kg_on = getenv("MAU_CONV_KG") == nullptr || atoi(getenv("MAU_CONV_KG")) != 0;
+    if (!done && kg_on && q.fast && q.nChunks % 2 == 0 && q.nChunks >= 4 && nItems <= ds.cus) {
+      MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, false, false, 2>), dim3(nItems), dim3(NW * 2 * 64), 2 * G::LDS, st, q, nPixTiles, nCt, nItems);
       done = true;
     }
   }
@@ -1076,6 +1137,14 @@ int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   static_assert(v2::Geo<128, 2, 8>::WM == 4 && v2::Geo<128, 4, 8>::WM == 4 && v2::Geo<64, 2, 4>::WM == 4, "slab rows");
   static_assert(v2::Geo<64, 1, 4>::WM == 4 && v2::Geo<64, 1, 4>::TH == 8, "slab rows");
   return wm * N * ceil_div(H, th) * ceil_div(W, v2::TW);
+}
+
+// which tile variant the 16-bit kernel runs for a layer: tile rows, waves per workgroup, output channels per workgroup
+void conv_bf16_v2_variant(int N, int H, int W, int Cout, int* th, int* nw, int* bn) {
+  const v2::Variant v = v2::pick_variant(round_up(Cout, 64), N, H, W);
+  *th = v.th;
+  *nw = v.nw;
+  *bn = v.bn;
 }
 
 int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {

@@ -410,6 +410,10 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   if (smax < 1) smax = 1;
   if (smax > 1024) smax = 1024;
   if ((size_t)smax > cap) smax = (int)cap;
+  if (const char* f = getenv("MAU_WGRAD_SPLITS_FORCE")) {      // timing experiments only (read per call): a given split count, clipped
+    const int s = atoi(f);
+    if (s >= 1) return s > smax ? smax : s;
+  }
   int best = 1;
   double best_score = -1.0;
   const long cus = launch_cus();                    // the device's CUs, or the calling thread's budget (mau_set_cu_budget)

@@ -45,6 +45,15 @@ template <int OFF>
 __device__ __forceinline__ void lds_write_b32(unsigned addr, unsigned v) {
   asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+// the accumulator hand-over of the K-group variants (once per item): 16 bytes per lane, waited for by the caller
+__device__ __forceinline__ void lds_write_f32x4(unsigned addr, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 lds_read_f32x4(unsigned addr) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // two fp32 -> one dword of two bf16 (round to nearest even): v_cvt_pk_bf16_f32

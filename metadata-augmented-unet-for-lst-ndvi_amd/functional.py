@@ -361,6 +361,7 @@ def _join_side_when_backward_ends(dev):
 # main chain run on the compute units the branch does not hold.  (wgrad CUs, dgrad CUs); 0 = the whole device.
 _WGRAD_CUS = int(os.environ.get("MAU_WGRAD_CUS", "0") or 0)
 _DGRAD_CUS = int(os.environ.get("MAU_DGRAD_CUS", "0") or 0)
+_SHARE_MIN_HW = int(os.environ.get("MAU_SHARE_MIN_HW", "0") or 0)     # only layers of at least this many pixels per image share the chip
 
 
 # launch order inside ConvBNReLU.backward: None = the network's choice (BNState.dgrad_first), "0" / "1" = forced (same-call A/B)
@@ -715,7 +716,7 @@ class ConvBNReLU(torch.autograd.Function):
         deferred = False
         dfull = None
         # the two chains share the chip by compute units only where both exist: a deferred weight gradient beside a data gradient
-        share = side is not None and overlap >= 2 and need_dx and not st.first
+        share = side is not None and overlap >= 2 and need_dx and not st.first and H * W >= _SHARE_MIN_HW
         wcus, dcus = (_WGRAD_CUS, _DGRAD_CUS) if share else (0, 0)
         if (st.dgrad_first if _DGRAD_FIRST is None else _DGRAD_FIRST == "1") and need_dx and needs[3] and side is not None:
             # the main chain's data gradient is enqueued BEFORE the branch's weight gradient (both need only dy: whichever is

@@ -43,7 +43,11 @@ for name, cin, cout, h in layers:
     acc = torch.empty(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, cout, cin), device="cuda")
     ns = lib.mau_conv3x3_wgrad_splits(code, N, H, W, cout, cin)
     dw = torch.empty_like(w)
-    f_fwd = lambda: call("mau_conv3x3_fwd", x.data_ptr(), x.shape[-1], cin, None, None, 0, wf.data_ptr(), bias.data_ptr(), None, None, y.data_ptr(), y.shape[-1], cout, slab.data_ptr(), code, N, H, W, st)
+    # EPI=post: the forward column times the INFERENCE epilogue (eval-mode BatchNorm + ReLU folded in, no statistics slab)
+    post = os.environ.get("EPI") == "post"
+    psc, psh = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda")
+    f_fwd = lambda: call("mau_conv3x3_fwd", x.data_ptr(), x.shape[-1], cin, None, None, 0, wf.data_ptr(), bias.data_ptr(), psc.data_ptr() if post else None,
+                         psh.data_ptr() if post else None, y.data_ptr(), y.shape[-1], cout, None if post else slab.data_ptr(), code, N, H, W, st)
     f_dg = lambda: call("mau_conv3x3_fwd", dy.data_ptr(), dy.shape[-1], cout, None, None, 0, wd.data_ptr(), None, None, None, dx.data_ptr(), dx.shape[-1], cin, None, code, N, H, W, st)
     f_wg = lambda: call("mau_conv3x3_wgrad", x.data_ptr(), x.shape[-1], cin, None, None, 0, dy.data_ptr(), dy.shape[-1], cout, acc.data_ptr(), code, N, H, W, st)
     fl = 2.0 * 9 * cin * cout * N * H * W

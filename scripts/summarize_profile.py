@@ -84,8 +84,20 @@ def family(pred):
 
 
 cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+
+
+def calls_of(*needles):
+    return sum(int(r["Calls"]) for r in rows if any(n in r["Name"] for n in needles))
+
+
+# what the profiled command ran, from its own launch counts: one optimizer launch per train step, one metadata-MLP forward per
+# network forward (train or eval) -- warm-up, capture, timed regions, the read-back pass, the event pass and the latency forwards
+n_steps = calls_of("adamw_pack_kernel") or calls_of("mse_kernel")
+n_fwd = calls_of("meta_mlp_fwd_kernel")
+ran = f"{n_steps} train steps + {max(0, n_fwd - n_steps)} eval-mode forwards, counted from the launches of this profile"
 summary = {
-    "command": f"rocprofv3 --kernel-trace [--stats | --pmc <set>] --output-format csv -- {cmd}   (4 timed-region steps + 7 eval forwards; scripts/profile.sh, scripts/summarize_profile.py)",
+    "command": f"rocprofv3 --kernel-trace [--stats | --pmc <set>] --output-format csv -- {cmd}   ({ran}; scripts/profile.sh, scripts/summarize_profile.py)",
+    "train_steps_in_profile": n_steps, "eval_forwards_in_profile": max(0, n_fwd - n_steps),
     "correction": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE tallies 128-B requests as 64 B for wide coalesced reads incl. LDS-DMA; WRITE_SIZE is exact for 16-B stores (MI355X_MICROARCH.md, HBM section)",
     "mfma_busy_fraction": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs)",
     "conv3x3_bf16_kernel (dominant: forward + data gradient)": family(lambda n: "conv3x3_bf16_kernel" in n),
