@@ -414,18 +414,28 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
     const int s = atoi(f);
     if (s >= 1) return s > smax ? smax : s;
   }
+  // Which split count: a workgroup costs its nTiles / s pixel-tile iterations plus a fixed overhead OV (pipeline fill, the 147-295 KB
+  // slab it writes and the second stage reads back), and the launch runs in ceil(workgroups / CUs) rounds:
+  //     cost(s) = rounds(s) * (nTiles / s + OV),     OV = 16 iterations of the 4 x 32 tiling, 10 of the 8 x 16 one
+  // (fitted to scripts/wgrad_split_probe.py, profiles/r5/wgrad_split_probe.txt: wgrad + second stage per layer over forced split
+  // counts).  Round 4's rule -- fill whole rounds, prefer fewer splits -- agrees on fifteen of the U-Net's eighteen layers; on the
+  // K-heavy ones (hundreds of (co,ci) tiles before any split) it bought the last points of grid fill with two more rounds of slabs:
+  // 1536->512 at 32^2 s = 8 -> 5 (371 -> 355 us, 226 -> 142 MB of slabs), 768->256 at 64^2 s = 32 -> 8 (363 -> 358 us, 226 -> 57 MB),
+  // 576->1024 at 16^2 s = 7 -> 3 (111 -> 91 us, 149 -> 64 MB).  Ties go to the smaller s (less slab traffic).
   int best = 1;
-  double best_score = -1.0;
+  double best_cost = 1e300;
   const long cus = launch_cus();                    // the device's CUs, or the calling thread's budget (mau_set_cu_budget)
   const int xcds = wg2::wgrad_xcd_order() ? device_shape().xcds : 1;
+  const double ov = v.k16 ? 16.0 : 10.0;
+  static const bool r4_rule = getenv("MAU_WGRAD_SPLIT_MODEL") != nullptr && atoi(getenv("MAU_WGRAD_SPLIT_MODEL")) == 0;    // A/B: round 4's rule
   for (int s = 1; s <= smax; ++s) {                // s = workgroups along the split axis = partial slabs
     if (s >= xcds && s % xcds != 0) continue;      // whole splits per XCD (see the kernel's work-item order)
     const long blocks = (long)outTiles * s;
     const long rounds = (blocks + cus - 1) / cus;
-    const double eff = (double)blocks / (double)(rounds * cus);
-    const double score = eff - 0.0015 * s;
-    if (score > best_score + 1e-9) {
-      best_score = score;
+    const double cost = r4_rule ? 0.0015 * s - (double)blocks / (double)(rounds * cus)      // (grid fill first, then fewer splits)
+                                : (double)rounds * ((double)ceil_div(nTiles, s) + ov);
+    if (cost < best_cost - 1e-9 * (best_cost < 0 ? -best_cost : best_cost)) {
+      best_cost = cost;
       best = s;
     }
   }

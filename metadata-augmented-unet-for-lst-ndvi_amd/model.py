@@ -594,6 +594,6 @@ class UrbanPredictor(nn.Module):
         self.model.freeze_inference(False)
         return super().load_state_dict(*args, **kwargs)
 
-    def set_sync_bn(self, group=None, world_size=None):
-        self.model.set_sync_bn(group, world_size)
+    def set_sync_bn(self, group=None, world_size=None, direct=None):
+        self.model.set_sync_bn(group, world_size, direct)
         return self

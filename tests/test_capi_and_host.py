@@ -296,3 +296,37 @@ def test_pmc_record_belongs_to_the_library_in_the_tree():
     stale = {k: v["lib_sha256"][:12] for k, v in latest.items() if v["lib_sha256"] != have}
     if stale:
         pytest.skip(f"{recs[-1]} was measured on another build ({stale}; this tree builds {have[:12]}): re-run scripts/r4_final.sh + r4_records2.sh")
+
+
+def test_hand_counted_lds_waits_hold_in_the_emitted_isa():
+    """ADVICE r4 (conv3x3_first.hip ``tr_frag``, conv3x3_wgrad16 / _wgrad_bf16 ``tr_read``): fragment reads issued from inline asm are
+    invisible to the compiler's wait-count pass; that no copy or consumer of a fragment register sits in front of the hand-counted
+    ``s_waitcnt lgkmcnt(N)`` is a property of the register allocation of THIS build.  ``scripts/check_lds_waits.py`` walks the
+    disassembly of every kernel of the in-tree objects with the hardware's in-order LDS model and must find no such instruction."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lds_waits", os.path.join(ROOT, "scripts", "check_lds_waits.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    # the checker itself: a copy of a transposed-read half in front of the wait IS reported, behind it is not; counted waits are honoured
+    bad = "0000000000001000 <k>:\n\tds_read_b64_tr_b16 v[10:11], v1  // 000000001000: 0\n\tds_read_b64_tr_b16 v[12:13], v1 offset:512  // 000000001008: 0\n" \
+          "\tv_mov_b32_e32 v20, v12  // 000000001010: 0\n\ts_waitcnt lgkmcnt(0)  // 000000001014: 0\n\tv_mov_b32_e32 v21, v10  // 000000001018: 0\n\ts_endpgm  // 00000000101c: 0\n"
+    h, r = chk.check(bad, "synthetic")
+    assert r == 2 and len(h) == 1 and "v20, v12" in h[0][2]
+    counted = "0000000000001000 <k>:\n\tds_read_b128 v[0:3], v9  // 000000001000: 0\n\tds_read_b128 v[4:7], v9 offset:16  // 000000001008: 0\n" \
+              "\ts_waitcnt lgkmcnt(1)  // 000000001010: 0\n\tv_mfma_f32_16x16x32_bf16 v[20:23], v[0:3], v[0:3], v[20:23]  // 000000001014: 0\n" \
+              "\tv_mfma_f32_16x16x32_bf16 v[20:23], v[4:7], v[4:7], v[20:23]  // 00000000101c: 0\n\ts_endpgm  // 000000001024: 0\n"
+    h, r = chk.check(counted, "synthetic")
+    assert r == 2 and len(h) == 1 and "v[4:7]" in h[0][2]            # the first fragment has landed, the second has not
+    objs = [o for o in __import__("glob").glob(os.path.join(ROOT, "metadata-augmented-unet-for-lst-ndvi_amd", "csrc", "*.o")) if not o.endswith(".asan.o")]
+    assert len(objs) >= 15, "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
+    import tempfile
+    total, hazards = 0, []
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in sorted(objs):
+            asm = chk.disassemble(o, tmp)
+            if asm:
+                h, r = chk.check(asm, os.path.basename(o))
+                total += r
+                hazards += h
+    assert total > 10000, total                                        # (the convolution kernels alone issue thousands of fragment reads)
+    assert not hazards, hazards[:5]
