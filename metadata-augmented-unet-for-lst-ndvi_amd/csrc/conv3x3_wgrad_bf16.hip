@@ -421,7 +421,10 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   // counts).  Round 4's rule -- fill whole rounds, prefer fewer splits -- agrees on fifteen of the U-Net's eighteen layers; on the
   // K-heavy ones (hundreds of (co,ci) tiles before any split) it bought the last points of grid fill with two more rounds of slabs:
   // 1536->512 at 32^2 s = 8 -> 5 (371 -> 355 us, 226 -> 142 MB of slabs), 768->256 at 64^2 s = 32 -> 8 (363 -> 358 us, 226 -> 57 MB),
-  // 576->1024 at 16^2 s = 7 -> 3 (111 -> 91 us, 149 -> 64 MB).  Ties go to the smaller s (less slab traffic).
+  // 576->1024 at 16^2 s = 7 -> 3 (111 -> 91 us, 149 -> 64 MB).  Ties go to the smaller s (less slab traffic).  A split count that is
+  // not a whole number per XCD runs in the plain work-item order, where every XCD reads every pixel range: charged 10 % -- on
+  // 1536->512 at 32^2 the probe's fastest count (s = 5: 355 us against 371) moved 702 MB through the fabric where s = 8 moves 428
+  // (profiles/r5/layer_traffic.txt of the first records), for 4 % of one launch that the step does not see; it stays at s = 8.
   int best = 1;
   double best_cost = 1e300;
   const long cus = launch_cus();                    // the device's CUs, or the calling thread's budget (mau_set_cu_budget)
@@ -433,7 +436,7 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
     const long blocks = (long)outTiles * s;
     const long rounds = (blocks + cus - 1) / cus;
     const double cost = r4_rule ? 0.0015 * s - (double)blocks / (double)(rounds * cus)      // (grid fill first, then fewer splits)
-                                : (double)rounds * ((double)ceil_div(nTiles, s) + ov);
+                                : (double)rounds * ((double)ceil_div(nTiles, s) + ov) * ((xcds > 1 && s % xcds != 0 && outTiles >= xcds) ? 1.10 : 1.0);
     if (cost < best_cost - 1e-9 * (best_cost < 0 ? -best_cost : best_cost)) {
       best_cost = cost;
       best = s;

@@ -235,7 +235,8 @@ ASYMMETRIC_WORKER = textwrap.dedent(r'''
 ''')
 
 
-def test_under_torchrun_an_asymmetric_failure_still_falls_back(tmp_path):
+@pytest.mark.parametrize("nproc", [2, 8])
+def test_under_torchrun_an_asymmetric_failure_still_falls_back(tmp_path, nproc):
     """one rank's worker dies at once, its peer hangs.  The early supervisor must not give up waiting for the next
     attempt's port before the leader's supervisor has ended ITS worker -- and the leader must not wait for the stage limit:
     the failed rank's flag ends the attempt everywhere."""
@@ -247,8 +248,8 @@ def test_under_torchrun_an_asymmetric_failure_still_falls_back(tmp_path):
     script.write_text(ASYMMETRIC_WORKER)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MAU_DP_GRAPH")}
     env["MAU_BENCH_WORKER_SCRIPT"] = str(script)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29548",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", "29548",
+           os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)]              # (8 = the driver's launch line for the scaling run)
     t0 = time.monotonic()
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     took = time.monotonic() - t0

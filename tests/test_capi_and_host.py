@@ -46,8 +46,19 @@ def test_library_exports_every_header_symbol():
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 16, 16, 1024) == 32 * 4
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_BF16, 32, 16, 16, 1024) == 32 * 4
     assert _lib.lib.mau_conv3x3_num_pixel_tiles(_lib.MAU_F32, 2, 250, 250, 64) == 2 * 32 * 16
-    s = _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 32, 32, 512, 1536)
-    assert s >= 1 and (4 * 24 * s) % 256 == 0          # whole rounds of 256 CUs
+    # split-K count of the weight gradient: the fitted cost model rounds(s) * (nTiles / s + overhead) -- one round of 256 workgroups where
+    # the layer has few (co,ci) tiles, FEWER splits than whole rounds would take on the K-heavy layers (profiles/r5/wgrad_split_probe.txt)
+    assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 256, 256, 64, 64) == 256
+    assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 32, 32, 512, 1536) == 8      # (s = 5 is 4 % faster alone and moves 1.6x the bytes: plain work-item order)
+    assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 64, 64, 256, 768) == 8
+    assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 16, 16, 1024, 576) == 3
+    # ... and under a compute-unit budget (mau_set_cu_budget): sized for that many workgroups; rounded to whole CUs per XCD
+    assert _lib.lib.mau_set_cu_budget(100) == 0
+    assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 256, 256, 64, 64) == 96
+    assert _lib.lib.mau_set_cu_budget(0) == 100
+    assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 256, 256, 64, 64) == 256
+    assert _lib.conv3x3_variant(_lib.MAU_BF16, 32, 256, 256, 64) == (32, 4, 64) and _lib.conv3x3_variant(_lib.MAU_BF16, 32, 128, 128, 128) == (32, 8, 128)
+    assert _lib.conv3x3_variant(_lib.MAU_BF16, 1, 32, 32, 1024) == (8, 4, 64) and _lib.conv3x3_variant(_lib.MAU_F32, 2, 31, 17, 70)[2] == 64
     # the fp32 parity mode also writes split-K partial slabs (plain stores + fixed-order sum: no float atomics anywhere)
     s32 = _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_F32, 32, 32, 32, 512, 1536)
     assert 1 <= s32 <= 32 * 4 * 2 and s32 * 9 * 512 * 1536 * 4 <= 256 << 20
