@@ -367,6 +367,22 @@ __global__ __launch_bounds__(NW * KG * 64, 2) void conv3x3_bf16_kernel(ConvP p, 
       hp_or_row = row;
     }
   };
+  auto slot_of_at = [wave](int j, int ln, int& hp_or_row, int& c) {        // (the same for a given lane index)
+    const int q = wave + j * NW;
+    hp_or_row = -1;
+    c = 0;
+    if (q < HALO_Q) {
+      const int slot = q * 64 + ln;
+      const int hp = slot >> 1, ph = slot & 1;
+      c = 8 * (M16 ? ph : ph ^ halo_swz(hp % HS));      // (M16: the lane groups of its reads are conflict-free unswizzled)
+      hp_or_row = hp < HPIX ? hp : -1;
+    } else if (q < TOT_Q) {
+      const int slot = (q - HALO_Q) * 64 + ln;
+      const int row = slot >> 1, ph = slot & 1;
+      c = 8 * (M16 ? ph : ph ^ ((row >> 3) & 1));
+      hp_or_row = row;
+    }
+  };
 
   // per-lane source offsets of the item being LOADED (constant over its stages); -1 = zero page
   //   halo slot: linear pixel index (n*H + gy)*W + gx;   weight slot: element offset of the row inside a chunk's slab
@@ -393,16 +409,30 @@ __global__ __launch_bounds__(NW * KG * 64, 2) void conv3x3_bf16_kernel(ConvP p, 
   const int lim0v = (p.C1 == 0 && p.E == 0) ? p.ldx : p.C0, lim1v = p.E == 0 ? p.C0 + p.ldx1 : p.C0 + p.C1;
   unsigned long long embn_a = 0;
   int embn_off = 0;                 // byte offset of the loaded item's image inside the embedding matrix
+  // The slot coordinates below (hp / 18, hp % 18, tap * CoutPad + co for up to 10 slots) are loop-invariant, and the compiler hoists
+  // them out of the item loop -- 2-3 registers per slot.  Where the register file is full it then SPILLS them: 26 VGPRs in the
+  // inference-epilogue instantiation of <64,4,4> (its 16 coefficient registers), 10 in <128,4,8>'s, reloaded from scratch at the
+  // head and the tail of every item.  In the INFERENCE-epilogue forms the lane index is therefore made opaque once per call: nothing
+  // can be hoisted, the coordinates are recomputed per item (~15 VALU per slot in the shadow of the last stage pair), no spill:
+  // the 64->64 layers of the 512 x 512 inference 3-7 % faster (profiles/r5/slot_invariants_ab.txt).  Everywhere else the hoisted form
+  // stays, untouched: recomputing costs the two-stage-pair items of level 0 +4-6 % (statistics epilogue), and where those forms
+  // spill (8 registers in the two-source <64,4,4>) the reloads sit outside the multiply loop -- a hand-packed one-register-per-slot
+  // form was measured too and is 0.3 % slower on the step than what the compiler does by itself.  (Also recomputed: the 32x32x16-loop
+  // forms of the 64-wide four-row tilings -- odd stage counts at level 0, rare -- whose spilled coordinates came back BETWEEN MFMAs.)
+  constexpr bool SLOT_RECOMPUTE = EPI == EPI_POST || (!M16 && BN == 64 && MT == 4);
   auto setup = [&](const Item& it) {
     embn_a = emb_a + 2ull * (unsigned long long)((long long)it.n * Ev);
     embn_off = 2 * it.n * Ev;
+    int lane_o = lane;
+    if constexpr (SLOT_RECOMPUTE) asm volatile("" : "+v"(lane_o));
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
       const int q = wave + j * NW;
       off32[j] = -1;
       if (!ONE && j < HJ) off1[j < HJ ? j : 0] = -1;
       int hp_or_row, sc;
-      slot_of(j, hp_or_row, sc);
+      if constexpr (SLOT_RECOMPUTE) slot_of_at(j, lane_o, hp_or_row, sc);
+      else slot_of(j, hp_or_row, sc);
       if (q < HALO_Q) {
         const int hp = hp_or_row;
         if (hp >= 0) {

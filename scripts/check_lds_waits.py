@@ -41,6 +41,44 @@ def vregs(text):
     return out
 
 
+def code_object(obj, tmp):
+    """-> path of the gfx950 code object bundled in a host object file ('' if it carries none)"""
+    fat = os.path.join(tmp, os.path.basename(obj) + ".fatbin")
+    co = os.path.join(tmp, os.path.basename(obj) + ".co")
+    subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+    if not os.path.exists(fat) or os.path.getsize(fat) == 0:
+        return ""
+    r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}", "--unbundle"],
+                       capture_output=True, text=True)
+    return co if (r.returncode == 0 and os.path.exists(co) and os.path.getsize(co) > 0) else ""
+
+
+def kernel_resources(obj, tmp):
+    """[(kernel name, VGPRs, spilled VGPRs, scratch bytes per lane)] from the code object's metadata.  The matrix-core kernels must use
+    NO scratch: a spilled register is reloaded by a vector-memory load, which besides its latency sits in the vmcnt that the kernels'
+    hand-counted DMA waits count (round 5 found 8-26 spilled registers in five instantiations of the convolution kernel -- loop-invariant
+    slot coordinates hoisted out of the item loop -- invisible in the source)."""
+    co = code_object(obj, tmp)
+    if not co:
+        return []
+    txt = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    out, cur = [], {}
+    for line in txt.splitlines():
+        m = re.match(r"\s*\.(name|private_segment_fixed_size|vgpr_count|vgpr_spill_count):\s*(\S+)", line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2)
+        if k == "name":
+            if cur.get("name") and "vgpr_count" in cur:
+                out.append(cur)
+            cur = {"name": v}
+        else:
+            cur[k] = int(v)
+    if cur.get("name") and "vgpr_count" in cur:
+        out.append(cur)
+    return [(c["name"], c.get("vgpr_count", -1), c.get("vgpr_spill_count", 0), c.get("private_segment_fixed_size", 0)) for c in out]
+
+
 def disassemble(obj, tmp):
     fat = os.path.join(tmp, os.path.basename(obj) + ".fatbin")
     co = os.path.join(tmp, os.path.basename(obj) + ".co")
@@ -126,6 +164,27 @@ def check(asm, name):
         if op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load") or op.startswith("s_sendmsg") or op.startswith("s_memtime"):
             queue.append(set())
     return hazards, reads
+
+
+def scratch_in_mfma_region(asm):
+    """Scratch (spill) accesses BETWEEN the first and the last MFMA of a kernel's listing -- i.e. inside its multiply loops, where a
+    reload's latency stalls the matrix pipes and its vmcnt slot breaks the hand-counted DMA waits.  -> [(kernel, instruction)]"""
+    out, func, seen_mfma, pending = [], None, False, []
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            func, seen_mfma, pending = m.group(1), False, []
+            continue
+        ins = line.split("//")[0].strip()
+        if not ins or func is None:
+            continue
+        op = ins.split()[0]
+        if op.startswith("v_mfma"):
+            out += pending                       # scratch accesses seen since the previous MFMA lie between two MFMAs
+            pending, seen_mfma = [], True
+        elif op.startswith("scratch_") and seen_mfma:
+            pending.append((func, ins))
+    return out
 
 
 def main(argv):

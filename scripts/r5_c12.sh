@@ -1,0 +1,8 @@
+#!/bin/bash
+# final library of the round (inference-epilogue forms recompute their slot coordinates: no spills): whole GPU suite, then the records
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out/rec5
+timeout -k 10 1100 python -m pytest tests -m gpu -q > gpurun_out/rec5/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/rec5/pytest_gpu.log
+bash scripts/r5_records.sh
+bash scripts/r5_records2.sh

@@ -341,3 +341,24 @@ def test_hand_counted_lds_waits_hold_in_the_emitted_isa():
                 hazards += h
     assert total > 10000, total                                        # (the convolution kernels alone issue thousands of fragment reads)
     assert not hazards, hazards[:5]
+    # ... and no matrix-core kernel touches scratch INSIDE its multiply loops (between two MFMAs): a spilled register comes back through
+    # a vector-memory load whose latency would stall the matrix pipes and whose vmcnt slot the hand-counted DMA waits do not know
+    # about.  (Round 5 found 8-26 spilled registers in several instantiations of the convolution kernel -- loop-invariant slot
+    # coordinates of the loader, hoisted out of the item loop: reloaded at the head and the tail of an item, outside the multiply
+    # loop; the inference-epilogue forms now recompute them and spill nothing.)
+    kernels, in_loop, spilling = 0, [], []
+    hot = ("conv3x3_bf16_kernel", "wgrad16_kernel", "wgrad_bf16_kernel", "first_fwd_kernel", "first_wgrad_kernel", "conv3x3_igemm_kernel", "conv3x3_wgrad_kernel")
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in sorted(objs):
+            res = chk.kernel_resources(o, tmp)
+            kernels += len(res)
+            spilling += [(n, v, sp, sc) for n, v, sp, sc in res if any(t in n for t in hot) and sc]
+            if any(sc for n, v, sp, sc in res if any(t in n for t in hot)):
+                in_loop += [x for x in chk.scratch_in_mfma_region(chk.disassemble(o, tmp)) if any(t in x[0] for t in hot)]
+    assert kernels > 300, kernels
+    assert not in_loop, in_loop[:5]
+    assert not [k for k in spilling if "Li2ELb" in k[0] and "conv3x3_bf16_kernel" in k[0] and "ELb1ELb1E" in k[0]], spilling      # (inference-epilogue big-tile forms: none)
+    assert len(spilling) <= 16 and max([k[2] for k in spilling] or [0]) <= 16, spilling
+    bad = "0000000000001000 <k>:\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]  // 000000001000: 0\n\tscratch_load_dword v9, off, off  // 000000001008: 0\n" \
+          "\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]  // 000000001010: 0\n\tscratch_load_dword v9, off, off  // 000000001018: 0\n\ts_endpgm  // 00000000101c: 0\n"
+    assert len(chk.scratch_in_mfma_region(bad)) == 1                   # (the access behind the last MFMA is outside the multiply region)
