@@ -1,5 +1,6 @@
 #!/bin/bash
 # the loader's slot coordinates recomputed per item instead of hoisted-and-spilled (conv3x3_bf16.hip setup()): exactness, then
+# (before the call: cp the library of the commit to compare against to metadata-augmented-unet-for-lst-ndvi_amd/variants/libmau_hip_head.so -- the directory is git-ignored and travels with gpurun)
 # HEAD's library (variants/libmau_hip_head.so) against the new one, same call, alternating: per layer, step, inference
 set -u
 export TMPDIR=/tmp
