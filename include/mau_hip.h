@@ -45,22 +45,12 @@ extern "C" {
 typedef void* mau_stream_t;
 
 /* ---- library ---------------------------------------------------------- */
-#define MAU_ABI_VERSION 4  /* 2: single-launch reductions (tickets), multi-tensor weight pack, fused BatchNorm passes; 3: first-layer kernels; 4: mau_set_cu_budget */
+#define MAU_ABI_VERSION 5  /* 2: single-launch reductions (tickets), multi-tensor weight pack, fused BatchNorm passes; 3: first-layer kernels;
+                            * 4: mau_set_cu_budget (an experiment, measured a loss); 5: mau_set_cu_budget removed, mau_conv3x3_variant reports K groups */
 int mau_abi_version(void);
 const char* mau_last_error(void);
 /* 0 when the current HIP device is a gfx950 (MI355X); MAU_ERR_DEVICE otherwise. */
 int mau_device_check(void);
-
-/* Compute-unit budget of the CALLING THREAD's later launches (0 = the whole device; returns the previous value).  The backward
- * pass of src/train.py:252 has two independent chains once a layer's dy exists -- the data gradients with the BatchNorm passes
- * between them, and the weight gradients -- and every convolution / weight-gradient launch is sized to occupy all compute
- * units (persistent grid, LDS and registers full), so two of them on two streams take turns.  With a budget the 3x3 convolution
- * launches (mau_conv3x3_fwd*, 16-bit) use a persistent grid of `cus` workgroup slots and the weight gradient
- * (mau_conv3x3_wgrad*, mau_conv3x3_wgrad_splits / _acc_elems) picks its split-K count for `cus` workgroups: chains launched
- * with budgets b and total - b run side by side.  Rounded down to a whole number of CUs per XCD.  Results of the convolution
- * do not depend on it; the weight gradient's fixed-order split-K sum is a different (still deterministic) partition, so call
- * _splits / _acc_elems / _wgrad* / _unpack_wgrad of one layer under ONE budget. */
-int mau_set_cu_budget(int cus);
 
 /* ---- layout at the module boundary ------------------------------------ */
 /* maps (B,C,H,W) fp32 as handed over by collate_fn (src/dataset.py:99-106) -> NHWC-ld. */
@@ -109,7 +99,8 @@ int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout);
  * pixel rows of a workgroup tile (16 pixels wide), waves per workgroup, output channels per workgroup -- written to HOST ints.
  * 16-bit: (64,8,64) = <64,4,8>, (32,4,64) = <64,4,4> (two workgroups per CU, level 0), (32,8,128) = <128,4,8>, (16,..) / (8,..) =
  * the small-image forms; MAU_F32: the fp32 kernel's one tiling. */
-int mau_conv3x3_variant(int dtype, int N, int H, int W, int Cout, int* tile_rows_host, int* waves_host, int* cout_block_host);
+int mau_conv3x3_variant(int dtype, int N, int H, int W, int Cin, int Cout, int* tile_rows_host, int* waves_host, int* cout_block_host,
+                        int* k_groups_host);
 /* The network's FIRST convolution (reference src/model.py:222 / :67 conv0_0.conv1; nn.Conv2d(spatial_channels, 64, 3, padding=1),
  * src/model.py:12) for inputs of at most mau_conv3x3_first_max_channels() = 8 channels, 16-bit modes: reads the input AS THE
  * REFERENCE'S collate_fn DELIVERS IT -- x (N,Cin,H,W) fp32 contiguous (src/dataset.py:99-106) -- and the fp32 master weights

@@ -28,7 +28,6 @@ PROTOTYPES = {
     "mau_abi_version": (_i, []),
     "mau_last_error": (C.c_char_p, []),
     "mau_device_check": (_i, []),
-    "mau_set_cu_budget": (_i, [_i]),
     "mau_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_pack_tile_onehot": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mau_flip_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -143,11 +142,12 @@ def check(status: int, what: str = ""):
         raise MauError(f"libmau_hip {what} failed (status {status}): {msg.decode() if msg else '?'}")
 
 
-def conv3x3_variant(dtype: int, N: int, H: int, W: int, Cout: int):
-    """(tile rows, waves per workgroup, output channels per workgroup) of the convolution variant that runs such a layer."""
-    th, nw, bn = C.c_int(), C.c_int(), C.c_int()
-    check(lib.mau_conv3x3_variant(dtype, N, H, W, Cout, C.byref(th), C.byref(nw), C.byref(bn)), "mau_conv3x3_variant")
-    return th.value, nw.value, bn.value
+def conv3x3_variant(dtype: int, N: int, H: int, W: int, Cout: int, Cin: int = 0):
+    """(tile rows, waves per workgroup, output channels per workgroup, K groups per workgroup) of the convolution variant that runs
+    such a layer; ``Cin = 0``: input channels unknown (K groups reported as 1)."""
+    th, nw, bn, kg = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    check(lib.mau_conv3x3_variant(dtype, N, H, W, Cin, Cout, C.byref(th), C.byref(nw), C.byref(bn), C.byref(kg)), "mau_conv3x3_variant")
+    return th.value, nw.value, bn.value, kg.value
 
 
 def call(name: str, *args):

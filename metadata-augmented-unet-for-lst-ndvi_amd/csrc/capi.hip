@@ -14,10 +14,6 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// Compute-unit budget of the calling thread's launches (mau_set_cu_budget): 0 = the whole device.
-static thread_local int g_cu_budget = 0;
-int cu_budget() { return g_cu_budget; }
-
 int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -34,12 +30,6 @@ extern "C" {
 int mau_abi_version(void) { return MAU_ABI_VERSION; }
 
 const char* mau_last_error(void) { return mau::g_err; }
-
-int mau_set_cu_budget(int cus) {
-  const int prev = mau::g_cu_budget;
-  mau::g_cu_budget = cus > 0 ? cus : 0;
-  return prev;
-}
 
 int mau_device_check(void) {
   int dev = 0;

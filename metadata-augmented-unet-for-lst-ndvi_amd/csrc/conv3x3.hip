@@ -542,15 +542,18 @@ int mau_conv3x3_pack_weights_multi(const void* descs, int n, int total_tiles, in
   return check_launch("pack_weights_multi_kernel");
 }
 
-int mau_conv3x3_variant(int dtype, int N, int H, int W, int Cout, int* tile_rows_host, int* waves_host, int* cout_block_host) {
-  MAU_REQUIRE(tile_rows_host && waves_host && cout_block_host && N > 0 && H > 0 && W > 0 && Cout > 0, "conv3x3_variant: bad arguments");
+int mau_conv3x3_variant(int dtype, int N, int H, int W, int Cin, int Cout, int* tile_rows_host, int* waves_host, int* cout_block_host,
+                        int* k_groups_host) {
+  MAU_REQUIRE(tile_rows_host && waves_host && cout_block_host && k_groups_host && N > 0 && H > 0 && W > 0 && Cin >= 0 && Cout > 0,
+              "conv3x3_variant: bad arguments");
   if (dtype == MAU_F32) {
     *tile_rows_host = TH;
     *waves_host = 4;
     *cout_block_host = 64;
+    *k_groups_host = 1;
     return MAU_OK;
   }
-  conv_bf16_v2_variant(N, H, W, Cout, tile_rows_host, waves_host, cout_block_host);
+  conv_bf16_v2_variant(N, H, W, Cin, Cout, tile_rows_host, waves_host, cout_block_host, k_groups_host);
   return MAU_OK;
 }
 

@@ -187,6 +187,17 @@ inline constexpr PairSched kPairSched{};
 template <int MT>
 inline constexpr StageSched<MT> kStageSched{};
 
+// Two K groups per workgroup (KG = 2 below): which tilings have the form, and when the launcher takes it -- the layer leaves every CU
+// at most ONE 4-wave workgroup (nItems <= CUs: single-tile inference at the deep levels), an even stage count (same barriers in both
+// groups) of at least four.  The rule depends on the batch and on the device's CU count, and the two groups' partial sums are added in
+// a fixed order (group 0 + group 1): the same tile can therefore differ in the last bits between B = 1 and B = 8.
+// MAU_CONV_KG=0 switches it off (the A/B and test switch).
+constexpr bool has_k_groups(int bn, int mt, int nw) { return bn == 64 && nw == 4 && mt <= 2; }
+static inline bool k_groups_rule(int nChunks, int nItems) {
+  static const bool kg_on = getenv("MAU_CONV_KG") == nullptr || atoi(getenv("MAU_CONV_KG")) != 0;
+  return kg_on && nChunks % 2 == 0 && nChunks >= 4 && nItems <= device_shape().cus;
+}
+
 // One (pixel tile, cout tile) work item.
 struct Item {
   int pixTile, n, ty0, tx0, co0;
@@ -1011,7 +1022,7 @@ static int launch(const ConvP& p, hipStream_t st) {
     MAU_LDS_ATTR(G::LDS, &conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>);
     MAU_LDS_ATTR(G::LDS, (&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true, true>));
   }
-  constexpr bool HAS_KG = BN == 64 && NW == 4 && MT <= 2 && EPI != EPI_STATS;       // the under-filled-layer forms <64,1,4> / <64,2,4>
+  constexpr bool HAS_KG = has_k_groups(BN, MT, NW) && EPI != EPI_STATS;       // the under-filled-layer forms <64,1,4> / <64,2,4>
   if constexpr (HAS_KG) MAU_LDS_ATTR(2 * G::LDS, (&conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, false, false, 2>));
   const DeviceShape ds = device_shape();
   const int tilesX = ceil_div(p.W, TW), tilesY = ceil_div(p.H, G::TH);
@@ -1063,8 +1074,7 @@ static int launch(const ConvP& p, hipStream_t st) {
     // Two K groups per workgroup where the layer leaves every CU at most ONE 4-wave workgroup (single-tile inference at the deep
     // levels): the stages are dealt to two wave groups, a wave's chain of dependent MFMA groups halves and each SIMD
     // holds two waves.  Even stage counts only (same barriers in both groups); MAU_CONV_KG=0 switches it off (A/B).
-    static const bool kg_on = getenv("MAU_CONV_KG") == nullptr || atoi(getenv("MAU_CONV_KG")) != 0;
-    if (!done && kg_on && q.fast && q.nChunks % 2 == 0 && q.nChunks >= 4 && nItems <= ds.cus) {
+    if (!done && q.fast && k_groups_rule(q.nChunks, nItems)) {
       MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, false, false, 2>), dim3(nItems), dim3(NW * 2 * 64), 2 * G::LDS, st, q, nPixTiles, nCt, nItems);
       done = true;
     }
@@ -1090,7 +1100,7 @@ struct Variant {
 #ifndef MAU_CONV_L0_DEFAULT
 #define MAU_CONV_L0_DEFAULT 1
 #endif
-static inline Variant pick_variant(int CoutPad, int N, int H, int W) {
+static inline Variant pick_variant(int CoutPad, int N, int H, int W, int Cin) {
   static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 64;
   const bool wide = CoutPad % 128 == 0;
   // A 128-multiple layer whose 16-row items would keep fewer than half of the CUs busy (single-tile inference at the deep levels:
@@ -1159,7 +1169,7 @@ int launch_conv_bf16_tu_e2_f1(const ConvP&, int, int, int, hipStream_t);
 // rows of the BatchNorm partial-sum slab: one per (pixel tile, wave row of the workgroup)
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
   const int CoutPad = round_up(Cout, 64);
-  const v2::Variant v = v2::pick_variant(CoutPad, N, H, W);
+  const v2::Variant v = v2::pick_variant(CoutPad, N, H, W, 0);     // (the slab geometry must not depend on Cin: see pick_variant's level-0 rule)
   const int th = v.th;
   const int wm = (v.bn == 64 && v.nw == 8) ? v2::Geo<64, 2, 8>::WM : 4;    // <128,*,8>, <64,2,4>, <64,4,4>: 4 wave rows; <64,2,8>, <64,4,8>: 8
   static_assert(v2::Geo<64, 4, 4>::WM == 4 && v2::Geo<64, 4, 4>::TH == 32, "slab rows");
@@ -1170,11 +1180,20 @@ int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout) {
 }
 
 // which tile variant the 16-bit kernel runs for a layer: tile rows, waves per workgroup, output channels per workgroup
-void conv_bf16_v2_variant(int N, int H, int W, int Cout, int* th, int* nw, int* bn) {
-  const v2::Variant v = v2::pick_variant(round_up(Cout, 64), N, H, W);
+// ... and, given the layer's input channels (a single-source layer on the buffer-addressed loader, plain or inference epilogue),
+// the number of K groups per workgroup (2 = the under-filled-layer form, see k_groups_rule)
+void conv_bf16_v2_variant(int N, int H, int W, int Cin, int Cout, int* th, int* nw, int* bn, int* kg) {
+  const int CoutPad = round_up(Cout, 64);
+  const v2::Variant v = v2::pick_variant(CoutPad, N, H, W, Cin);
   *th = v.th;
   *nw = v.nw;
   *bn = v.bn;
+  const int mt = v.th / (2 * (v.nw / (v.bn / 64)));
+  const DeviceShape ds = device_shape();
+  const int nPixTiles = N * ceil_div(H, v.th) * ceil_div(W, v2::TW);
+  const int nItems = round_up(nPixTiles, nPixTiles < ds.xcds ? 1 : ds.xcds) * (CoutPad / v.bn);
+  const bool m16 = mt == 4 && Cin > 0 && ceil_div(Cin, v2::KC) % 2 == 0;
+  *kg = (Cin > 0 && Cin % v2::KC == 0 && !m16 && v2::has_k_groups(v.bn, mt, v.nw) && v2::k_groups_rule(ceil_div(Cin, v2::KC), nItems)) ? 2 : 1;
 }
 
 int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
@@ -1183,7 +1202,7 @@ int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st) {
     return MAU_ERR_ARG;
   }
   static_assert(v2::EPI_PLAIN == 0 && v2::EPI_STATS == 1 && v2::EPI_POST == 2, "translation-unit names");
-  const v2::Variant v = v2::pick_variant(p.CoutPad, p.N, p.H, p.W);
+  const v2::Variant v = v2::pick_variant(p.CoutPad, p.N, p.H, p.W, p.C0 + p.C1 + p.E);
   const int th = v.th, nw = v.nw, bn = v.bn;
   if (p.post_scale != nullptr) return f16 ? launch_conv_bf16_tu_e2_f1(p, th, nw, bn, st) : launch_conv_bf16_tu_e2_f0(p, th, nw, bn, st);   // (a post-affine launch carries no slab)
   if (p.slab != nullptr) return f16 ? launch_conv_bf16_tu_e1_f1(p, th, nw, bn, st) : launch_conv_bf16_tu_e1_f0(p, th, nw, bn, st);

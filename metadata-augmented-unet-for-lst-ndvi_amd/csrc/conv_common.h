@@ -69,7 +69,7 @@ struct PackKC {
 
 int launch_conv_bf16_v2(const ConvP& p, bool f16, hipStream_t st);   // 16-bit kernels: bf16 or (f16 = true) fp16 operands
 int conv_bf16_v2_num_pixel_tiles(int N, int H, int W, int Cout);
-void conv_bf16_v2_variant(int N, int H, int W, int Cout, int* th, int* nw, int* bn);
+void conv_bf16_v2_variant(int N, int H, int W, int Cin, int Cout, int* th, int* nw, int* bn, int* kg);
 int launch_wgrad_bf16_v2(const WgradP& p, bool f16, hipStream_t st);      // writes nsplit partial slabs (plain stores)
 int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin);
 

@@ -226,17 +226,9 @@ static inline DeviceShape device_shape() {
   }
   return cache[dev];
 }
-// Compute units the calling thread's persistent grids / split-K counts are sized for: the device's, or the budget set through
-// mau_set_cu_budget() (a whole number of CUs per XCD, at least one) -- two kernels of independent streams then share the chip by
-// CU instead of taking turns.  Tile variants and slab geometries never depend on it.
-int cu_budget();
-static inline int launch_cus() {
-  const DeviceShape ds = device_shape();
-  const int b = cu_budget();
-  if (b <= 0 || b >= ds.cus) return ds.cus;
-  const int per = b / ds.xcds;
-  return (per < 1 ? 1 : per) * ds.xcds;
-}
+// Compute units a persistent grid / a split-K count is sized for: the whole device.  (Round 5 measured a per-thread budget that
+// let two chains of the backward pass share the chip by CU: a loss at every split, EXPERIMENTS.md "Round 5 #1"; removed in ABI 5.)
+static inline int launch_cus() { return device_shape().cus; }
 // dynamic-LDS opt-in of a kernel, once per device (the attribute is per device, a process may drive several)
 #define MAU_LDS_ATTR(bytes, ...)                                                                                        \
   do {                                                                                                                  \

@@ -179,16 +179,20 @@ def destroy_comms(abort: bool = False):
 class CollectiveWatchdog:
     """A directly-issued ``ncclAllReduce`` has no timeout of its own (ProcessGroupNCCL's watchdog never sees it): a peer that
     died, or two communicators' kernels started in different orders on two ranks, is a silent hang.  The training loop calls
-    ``kick()`` once per finished step (after a host read-back, so "finished" means the GPU was there); when no kick arrives for
-    ``timeout_s`` the watchdog thread says so, aborts the communicators (``ncclCommAbort``) and ends the process with a
-    non-zero code -- the launcher then ends the other ranks."""
+    ``kick()`` once per finished step (after a host read-back, so "finished" means the GPU was there) and once per validation batch;
+    checkpoint writing runs under ``paused()``.  When no kick arrives for ``timeout_s`` the watchdog thread says so, aborts the
+    communicators (``ncclCommAbort``, in a helper thread bounded by ``MAU_DIST_ABORT_TIMEOUT_S``: the abort may block too) and ends
+    the process with a non-zero code -- the launcher then ends the other ranks.  ``close()`` (or leaving the ``with`` block) ends the
+    thread: a caller that catches an exception of the loop must not be killed by a stale watchdog later."""
 
     def __init__(self, timeout_s: Optional[float] = None, exit_code: int = 86, _exit=os._exit):
         import threading
         import time
         self.timeout_s = float(os.environ.get("MAU_DIST_TIMEOUT_S", "600")) if timeout_s is None else float(timeout_s)
         self._exit, self._code, self._time = _exit, exit_code, time
+        self.abort_timeout_s = float(os.environ.get("MAU_DIST_ABORT_TIMEOUT_S", "20"))
         self._last = time.monotonic()
+        self._paused = 0
         self._stop = threading.Event()
         self.fired = False
         self._thread = threading.Thread(target=self._watch, daemon=True, name="mau-collective-watchdog")
@@ -197,19 +201,48 @@ class CollectiveWatchdog:
     def kick(self):
         self._last = self._time.monotonic()
 
+    def paused(self):
+        """Context manager for stretches that are not training steps and issue no collective of ours to wait for -- a validation pass,
+        checkpoint writing, the first fetch of an epoch: the clock stands still inside and restarts on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            self._paused += 1
+            try:
+                yield self
+            finally:
+                self._paused -= 1
+                self.kick()
+        return _cm()
+
     def _watch(self):
         while not self._stop.wait(min(1.0, self.timeout_s / 4)):
+            if self._paused > 0:
+                self._last = self._time.monotonic()
+                continue
             if self._time.monotonic() - self._last > self.timeout_s:
                 import sys
+                import threading
                 self.fired = True
                 print(f"mau_amd.dist: no training step finished for {self.timeout_s:.0f} s -- a collective is hung; aborting the RCCL "
                       f"communicators and leaving with code {self._code}", file=sys.stderr, flush=True)
-                destroy_comms(abort=True)
+                # ncclCommAbort can itself block (a peer that never answers): it runs in a helper thread under a bound, the exit does not wait for it
+                t = threading.Thread(target=destroy_comms, kwargs=dict(abort=True), daemon=True, name="mau-comm-abort")
+                t.start()
+                t.join(self.abort_timeout_s)
                 self._exit(self._code)
                 return
 
     def close(self):
         self._stop.set()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):

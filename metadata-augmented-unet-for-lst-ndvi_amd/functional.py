@@ -354,16 +354,6 @@ def _join_side_when_backward_ends(dev):
     torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
-# Sharing the chip between the two chains of the backward pass.  Every convolution / weight-gradient launch is sized
-# for all compute units (persistent grid, LDS and registers full), so the main chain's kernel and the branch's kernel take turns.
-# With a budget (mau_set_cu_budget) the branch's weight gradient picks its split-K count for W workgroups and the data gradient
-# launched beside it a persistent grid of total - W: they run side by side, and the HBM-bound BatchNorm passes that follow on the
-# main chain run on the compute units the branch does not hold.  (wgrad CUs, dgrad CUs); 0 = the whole device.
-_WGRAD_CUS = int(os.environ.get("MAU_WGRAD_CUS", "0") or 0)
-_DGRAD_CUS = int(os.environ.get("MAU_DGRAD_CUS", "0") or 0)
-_SHARE_MIN_HW = int(os.environ.get("MAU_SHARE_MIN_HW", "0") or 0)     # only layers of at least this many pixels per image share the chip
-
-
 # launch order inside ConvBNReLU.backward: None = the network's choice (BNState.dgrad_first), "0" / "1" = forced (same-call A/B)
 _DGRAD_FIRST = os.environ.get("MAU_BWD_DGRAD_FIRST")
 
@@ -715,9 +705,6 @@ class ConvBNReLU(torch.autograd.Function):
         side = _side_stream(dev) if (needs[3] and overlap and (need_dx or overlap >= 2)) else None
         deferred = False
         dfull = None
-        # the two chains share the chip by compute units only where both exist: a deferred weight gradient beside a data gradient
-        share = side is not None and overlap >= 2 and need_dx and not st.first and H * W >= _SHARE_MIN_HW
-        wcus, dcus = (_WGRAD_CUS, _DGRAD_CUS) if share else (0, 0)
         if (st.dgrad_first if _DGRAD_FIRST is None else _DGRAD_FIRST == "1") and need_dx and needs[3] and side is not None:
             # the main chain's data gradient is enqueued BEFORE the branch's weight gradient (both need only dy: whichever is
             # enqueued first takes the chip, the other follows when its workgroups retire); the branch still waits only for dy --
@@ -726,15 +713,12 @@ class ConvBNReLU(torch.autograd.Function):
             dy_ready.record()
             wd = ctx.wd if ctx.wd is not None else pack_conv_weights(weight, code, forward=False, dgrad=True)[1]
             dfull = torch.empty((N, H, W, pad8(Cin)), dtype=y.dtype, device=dev)
-            lib.mau_set_cu_budget(dcus)
             call("mau_conv3x3_fwd", dy.data_ptr(), ldy, Cout, None, None, 0, wd.data_ptr(), None, None, None, dfull.data_ptr(),
                  pad8(Cin), Cin, None, code, N, H, W, stream)
-            lib.mau_set_cu_budget(0)
             side.wait_event(dy_ready)
         if needs[3]:
             if side is not None and dfull is None:
                 side.wait_stream(torch.cuda.current_stream())           # dy is complete
-            lib.mau_set_cu_budget(wcus)                                     # (split count, slabs, launch and second stage under ONE budget)
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                 # (workspaces of the side stream's kernels belong to ITS allocator pool: freed here, re-used there)
                 acc = torch.empty(max(lib.mau_conv3x3_wgrad_acc_elems(code, N, H, W, Cout, Cin),
@@ -759,7 +743,6 @@ class ConvBNReLU(torch.autograd.Function):
                      emb_ws.data_ptr() if E else None, E, dy.data_ptr(), ldy, Cout, acc.data_ptr(), code, N, H, W, wstream)
                 call("mau_conv3x3_unpack_wgrad", acc.data_ptr(), lib.mau_conv3x3_wgrad_splits(code, N, H, W, Cout, Cin),
                      dw.data_ptr(), Cout, Cin, wstream)
-            lib.mau_set_cu_budget(0)
             if deferred:
                 for t in (x, x1, emb, dy, dw):                           # read / written over there after this function has returned
                     if t is not None:
@@ -773,10 +756,8 @@ class ConvBNReLU(torch.autograd.Function):
             ldd = pad8(Cin)
             if dfull is None:
                 dfull = torch.empty((N, H, W, ldd), dtype=y.dtype, device=dev)
-                lib.mau_set_cu_budget(dcus)
                 call("mau_conv3x3_fwd", dy.data_ptr(), ldy, Cout, None, None, 0, wd.data_ptr(), None, None, None, dfull.data_ptr(),
                      ldd, Cin, None, code, N, H, W, stream)
-                lib.mau_set_cu_budget(0)
             Ct = st.C0 + C1
             if E and needs[2]:
                 demb = torch.empty((N, E), **f32)

@@ -13,6 +13,7 @@ parallel under ``torch.distributed.run`` (RCCL; eager step with overlapped colle
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Optional
 
@@ -41,7 +42,7 @@ def synthetic_batch(batch_size: int, device, gen: torch.Generator):
             mk(batch_size, len(ds.target_channels), e, e))
 
 
-def validate(model: torch.nn.Module, loader, criterion):
+def validate(model: torch.nn.Module, loader, criterion, watchdog=None):
     """Loss on the validation set (src/train.py:20-60): eval mode, no_grad, every batch's ``total`` weighted by its sample
     count; a batch whose criterion raises ValueError is skipped; the model is put back into training mode.
     Returns (mean loss, {}) -- ``float('inf')`` when no batch counted.  (The reference additionally averages
@@ -58,6 +59,8 @@ def validate(model: torch.nn.Module, loader, criterion):
                 if batch_loss is not None:
                     total += batch_loss.item() * len(inputs)
                     num += len(inputs)
+                    if watchdog is not None:
+                        watchdog.kick()                                                     # (a read-back: the GPU was there)
             except ValueError as e:
                 typer.echo(f"Skipping batch in validation due to error: {e}")
                 continue
@@ -144,47 +147,53 @@ def run(device: str = "", wandblog: bool = False, n_trials: int = 1, force_study
     dp_graph = sync is not None and os.environ.get("MAU_DP_GRAPH", "0") == "1"
     gstep = GraphedTrainStep(model, optimizer, criterion, clip_grad_norm=clip, grad_sync=sync) if (graph and (sync is None or dp_graph)) else None
     best, step, ckpt_path, history = float("inf"), 0, None, []
-    for epoch in range(epochs if epochs is not None else cfg.epochs):
-        model.train()
-        total, num = 0.0, 0
-        for _ in range(steps_per_epoch):
-            inputs, metadata, temp_series, _lengths, t1, t2, targets = synthetic_batch(cfg.batch_size, CONFIG.device, gen)
-            metadata_full = torch.cat([metadata, t1, t2], dim=1) if n_meta >= 8 else metadata  # src/train.py:244
-            if gstep is not None:
-                batch_loss = gstep(inputs, temp_series, metadata_full, targets)             # src/train.py:245-256 in one replay
-            else:
-                outputs = model(inputs, temp_series, metadata_full)                         # src/train.py:245
-                batch_loss = criterion(outputs, targets).get("total", None)                 # src/train.py:247-249
-                if sync is not None:
-                    sync.begin()
-                batch_loss.backward()
-                if sync is not None:
-                    sync.finish()
-                if clip > 0:
-                    torch.nn.utils.clip_grad_norm_(model.parameters(), clip)                # src/train.py:253-254
-                optimizer.step()
-                optimizer.zero_grad()
-            total += batch_loss.detach().cpu().item() * len(inputs)                         # src/train.py:258-260
+    try:
+        for epoch in range(epochs if epochs is not None else cfg.epochs):
+            model.train()
+            total, num = 0.0, 0
+            for _ in range(steps_per_epoch):
+                inputs, metadata, temp_series, _lengths, t1, t2, targets = synthetic_batch(cfg.batch_size, CONFIG.device, gen)
+                metadata_full = torch.cat([metadata, t1, t2], dim=1) if n_meta >= 8 else metadata  # src/train.py:244
+                if gstep is not None:
+                    batch_loss = gstep(inputs, temp_series, metadata_full, targets)             # src/train.py:245-256 in one replay
+                else:
+                    outputs = model(inputs, temp_series, metadata_full)                         # src/train.py:245
+                    batch_loss = criterion(outputs, targets).get("total", None)                 # src/train.py:247-249
+                    if sync is not None:
+                        sync.begin()
+                    batch_loss.backward()
+                    if sync is not None:
+                        sync.finish()
+                    if clip > 0:
+                        torch.nn.utils.clip_grad_norm_(model.parameters(), clip)                # src/train.py:253-254
+                    optimizer.step()
+                    optimizer.zero_grad()
+                total += batch_loss.detach().cpu().item() * len(inputs)                         # src/train.py:258-260
+                if watchdog is not None:
+                    watchdog.kick()                                                             # (the read-back above: the step HAS finished)
+                num += len(inputs)
+                step += 1
+            epoch_loss = total / max(num, 1)
+            val_loss, _ = validate(model, val_loader, criterion, watchdog)                      # src/train.py:286
+            history.append((epoch_loss, val_loss))
+            if rank == 0:
+                typer.echo(f"Epoch {epoch + 1} | step {step} | Train Loss: {epoch_loss:.6f} | Val Loss: {val_loss:.6f}")
+                if val_loss < best:                                                             # src/train.py:303-319
+                    best = val_loss
+                    name = f"{study_name}_trial_0_best_job{jobid}.pth"
+                    ckpt_path = os.path.join(CONFIG.MODELS_DIR, name)
+                    with (watchdog.paused() if watchdog is not None else contextlib.nullcontext()):   # slow storage is not a hung collective
+                        save_checkpoint(ckpt_path, model, optimizer, epoch=epoch, step=step, loss=best,
+                                        hyperparameters=hyper, model_type=model_type, study_name=study_name, trial_id=0,
+                                        metadata_input_length=n_meta)
             if watchdog is not None:
-                watchdog.kick()                                                             # (the read-back above: the step HAS finished)
-            num += len(inputs)
-            step += 1
-        epoch_loss = total / max(num, 1)
-        val_loss, _ = validate(model, val_loader, criterion)                                # src/train.py:286
+                # the other ranks would otherwise sit in the next step's first collective while rank 0 writes: everybody waits HERE, clock
+                # stopped, in a barrier of the process group (which has torch's own timeout behind it)
+                with watchdog.paused():
+                    dist.barrier()
+    finally:
         if watchdog is not None:
-            watchdog.kick()
-        history.append((epoch_loss, val_loss))
-        if rank == 0:
-            typer.echo(f"Epoch {epoch + 1} | step {step} | Train Loss: {epoch_loss:.6f} | Val Loss: {val_loss:.6f}")
-            if val_loss < best:                                                             # src/train.py:303-319
-                best = val_loss
-                name = f"{study_name}_trial_0_best_job{jobid}.pth"
-                ckpt_path = os.path.join(CONFIG.MODELS_DIR, name)
-                save_checkpoint(ckpt_path, model, optimizer, epoch=epoch, step=step, loss=best,
-                                hyperparameters=hyper, model_type=model_type, study_name=study_name, trial_id=0,
-                                metadata_input_length=n_meta)
-    if watchdog is not None:
-        watchdog.close()
+            watchdog.close()          # also when the loop raises: a caller that handles the exception must not be killed later
     return {"best": best, "model": model, "optimizer": optimizer, "checkpoint_path": ckpt_path, "history": history}
 
 

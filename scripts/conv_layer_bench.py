@@ -15,6 +15,10 @@ vgg("conv0_0", 6, 64, 64, S); vgg("conv1_0", 64, 128, 128, S // 2); vgg("conv2_0
 vgg("conv3_0", 256, 512, 512, S // 8); vgg("conv4_0", 576, 1024, 1024, S // 16)
 vgg("conv3_1", 1536, 512, 512, S // 8); vgg("conv2_1", 768, 256, 256, S // 4); vgg("conv1_1", 384, 128, 128, S // 2)
 vgg("conv0_1", 192, 64, 64, S)
+# EXTRA="name:cin:cout:h,...": further layers (e.g. the U-Net++'s full-resolution nodes x0_1..x0_4: 208 / 272 / 336 / 400 -> 64)
+for t in [t for t in os.environ.get("EXTRA", "").split(",") if t]:
+    nm, ci, co, hh = t.split(":")
+    layers.append((nm, int(ci), int(co), int(hh)))
 st = torch.cuda.current_stream().cuda_stream
 code = MAU_BF16; dt = torch.bfloat16
 def timeit(fn, reps=8):

@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
   SYM(mau_conv3x3_fwd) SYM(mau_conv3x3_fwd2) SYM(mau_conv3x3_wgrad2) SYM(mau_bn_relu_apply) SYM(mau_maxpool2x2_fwd)
   SYM(mau_linear_fwd) SYM(mau_resize_bilinear_fwd) SYM(mau_head_fwd) SYM(mau_lstm_fwd) SYM(mau_ssim_loss) SYM(mau_nchw_to_nhwc) SYM(mau_copy_channels) SYM(mau_emb_fold_fwd)
   SYM(mau_conv3x3_first_max_channels) SYM(mau_conv3x3_first_rows) SYM(mau_conv3x3_first_fwd) SYM(mau_conv3x3_first_wgrad_ws_elems) SYM(mau_conv3x3_first_wgrad)
-  if (p_mau_abi_version() != 4) return 5;
+  if (p_mau_abi_version() != 5) return 5;
   size_t acc = 0;
   for (int dt = MAU_F32; dt <= MAU_F16; ++dt) {
     if (p_mau_conv3x3_kc(dt) != 16) return 6;

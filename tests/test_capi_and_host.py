@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libmau_hip.so does not export {s}"
     assert sorted(_lib.PROTOTYPES) == syms, (set(_lib.PROTOTYPES) ^ set(syms))
-    assert _lib.lib.mau_abi_version() == 4
+    assert _lib.lib.mau_abi_version() == 5
     # pure host-side helpers of the ABI are callable without a GPU
     assert _lib.lib.mau_conv3x3_kc(_lib.MAU_BF16) == 16 and _lib.lib.mau_conv3x3_kc(_lib.MAU_F32) == 16
     assert _lib.lib.mau_conv3x3_packed_elems(_lib.MAU_BF16, 64, 6) == 1 * 9 * 64 * 16
@@ -52,13 +52,13 @@ def test_library_exports_every_header_symbol():
     assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 32, 32, 512, 1536) == 8      # (s = 5 is 4 % faster alone and moves 1.6x the bytes: plain work-item order)
     assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 64, 64, 256, 768) == 8
     assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 16, 16, 1024, 576) == 3
-    # ... and under a compute-unit budget (mau_set_cu_budget): sized for that many workgroups; rounded to whole CUs per XCD
-    assert _lib.lib.mau_set_cu_budget(100) == 0
-    assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 256, 256, 64, 64) == 96
-    assert _lib.lib.mau_set_cu_budget(0) == 100
-    assert _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_BF16, 32, 256, 256, 64, 64) == 256
-    assert _lib.conv3x3_variant(_lib.MAU_BF16, 32, 256, 256, 64) == (32, 4, 64) and _lib.conv3x3_variant(_lib.MAU_BF16, 32, 128, 128, 128) == (32, 8, 128)
-    assert _lib.conv3x3_variant(_lib.MAU_BF16, 1, 32, 32, 1024) == (8, 4, 64) and _lib.conv3x3_variant(_lib.MAU_F32, 2, 31, 17, 70)[2] == 64
+    # the tile variant a layer runs, and the number of K groups per workgroup (2 = the under-filled-layer form: at most one workgroup
+    # per CU, an even stage count >= 4; needs the layer's input channels)
+    assert _lib.conv3x3_variant(_lib.MAU_BF16, 32, 256, 256, 64) == (32, 4, 64, 1) and _lib.conv3x3_variant(_lib.MAU_BF16, 32, 128, 128, 128) == (32, 8, 128, 1)
+    assert _lib.conv3x3_variant(_lib.MAU_BF16, 1, 32, 32, 1024) == (8, 4, 64, 1) and _lib.conv3x3_variant(_lib.MAU_F32, 2, 31, 17, 70)[2] == 64
+    assert _lib.conv3x3_variant(_lib.MAU_BF16, 1, 32, 32, 1024, Cin=1024) == (8, 4, 64, 2)      # B = 1 conv4_0.conv2: 128 items on 256 CUs
+    assert _lib.conv3x3_variant(_lib.MAU_BF16, 8, 32, 32, 1024, Cin=1024)[3] == 1              # B = 8: the chip is full, one K group
+    assert _lib.conv3x3_variant(_lib.MAU_BF16, 1, 32, 32, 1024, Cin=48)[3] == 1                # three stages: odd, no K groups
     # the fp32 parity mode also writes split-K partial slabs (plain stores + fixed-order sum: no float atomics anywhere)
     s32 = _lib.lib.mau_conv3x3_wgrad_splits(_lib.MAU_F32, 32, 32, 32, 512, 1536)
     assert 1 <= s32 <= 32 * 4 * 2 and s32 * 9 * 512 * 1536 * 4 <= 256 << 20

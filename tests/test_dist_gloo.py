@@ -187,3 +187,42 @@ def test_collective_watchdog_aborts_and_exits_when_no_step_finishes():
     time.sleep(1.2)                                                  # ... then one never does
     assert wd.fired and codes == [86] and FakeComm.aborted and not D._COMMS
     wd.close()
+
+
+def test_collective_watchdog_pauses_closes_and_bounds_a_blocking_abort():
+    """a validation pass / checkpoint write is not a hung collective (``paused()``); a closed watchdog never fires (the
+    training loop closes it in ``finally``); an ``ncclCommAbort`` that blocks does not keep the process from leaving."""
+    import threading
+    import time
+    from mau_amd import dist as D
+
+    D._COMMS.clear()
+    codes = []
+    wd = D.CollectiveWatchdog(timeout_s=0.3, _exit=codes.append)
+    with wd.paused():
+        time.sleep(1.0)                                              # three timeouts' worth of "no step": paused, nothing happens
+    assert not wd.fired and not codes
+    time.sleep(0.15)
+    assert not wd.fired                                              # ... and leaving the block restarted the clock
+    with wd:                                                         # close() on the way out, also when the body raises
+        pass
+    time.sleep(0.8)
+    assert not wd.fired and not codes
+
+    release = threading.Event()
+
+    class BlockingComm:
+        def abort(self):
+            release.wait(10.0)
+
+    D._COMMS[(2, "grad", 0)] = (object(), BlockingComm())
+    wd = D.CollectiveWatchdog(timeout_s=0.3, _exit=codes.append)
+    wd.abort_timeout_s = 0.3
+    t0 = time.monotonic()
+    while not codes and time.monotonic() - t0 < 5.0:
+        time.sleep(0.05)
+    assert codes == [86] and time.monotonic() - t0 < 3.0             # left although the abort is still blocked
+    release.set()
+    wd.close()
+    time.sleep(0.2)
+    D._COMMS.clear()

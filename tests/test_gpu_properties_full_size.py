@@ -9,8 +9,6 @@ U-Net's eighteen layer shapes) -- no CPU reference is affordable there, and none
     conv(shift(x)) == shift(conv(x)) bit for bit, for shifts that move every pixel to another tile position / another tile.  A wrong
     tap, a dropped halo column or an edge mask in ONE big-tile variant -- which the full-size oracle comparison's bf16 tolerance would
     hide (VERDICT r4, weak 1a) -- breaks this at every tile boundary;
-  * **grid size** (exact): the convolution under a compute-unit budget (``mau_set_cu_budget``: fewer persistent workgroups walk the same
-    items) returns the same bits;
   * **translation of the weight gradient** (exact on small-integer data, where every partial sum is an integer): the split-K sum over a
     shifted pixel set equals the unshifted one.
 
@@ -42,7 +40,7 @@ def env():
     assert torch.cuda.is_available()
     _lib.check(_lib.lib.mau_device_check(), "mau_device_check")
     if B >= 8:
-        assert _lib.conv3x3_variant(_lib.MAU_BF16, B, 256, 256, 64) == (32, 4, 64) and _lib.conv3x3_variant(_lib.MAU_BF16, B, 128, 128, 128) == (32, 8, 128)
+        assert _lib.conv3x3_variant(_lib.MAU_BF16, B, 256, 256, 64)[:3] == (32, 4, 64) and _lib.conv3x3_variant(_lib.MAU_BF16, B, 128, 128, 128)[:3] == (32, 8, 128)
     return F_, _lib
 
 
@@ -83,14 +81,6 @@ def test_forward_and_data_gradient_scale_and_translate_exactly(env, name, cin, c
         assert torch.equal(y2, y1 * 2), (name, what, "conv(2x) != 2 conv(x)")
         if slab1 is not None:
             assert torch.equal(slab2[:, :cpad], slab1[:, :cpad] * 2) and torch.equal(slab2[:, cpad:], slab1[:, cpad:] * 4), (name, "statistics")
-        # a compute-unit budget (mau_set_cu_budget: a smaller persistent grid walks the same work items) changes nothing
-        prev = _lib.lib.mau_set_cu_budget(96)
-        try:
-            yb = _conv(F_, _lib, x, C_in, pack, C_out)
-        finally:
-            assert _lib.lib.mau_set_cu_budget(prev) == 96
-        assert torch.equal(yb, y1), (name, what, "compute-unit budget")
-        del yb
         # translation: every pixel lands on another position of its tile, most on another wave strip or tile
         for dy_, dx_ in ((1, 1), (2, 0)) if h >= 32 else ((1, 1),):
             ys = _conv(F_, _lib, torch.roll(x, (dy_, dx_), dims=(1, 2)), C_in, pack, C_out)
