@@ -24,6 +24,38 @@ __device__ __forceinline__ float round_to(float v) {
   return opaque((float)(T)opaque(v));          // (a conversion and nothing else: mau_common.h, opaque)
 }
 
+// ---- packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on gfx950): two channels per vector instruction ----
+// Every operation below is the IEEE operation its scalar spelling is (fused multiply-add, multiply, add; conversions per element), so a
+// kernel written on pairs returns the bits of the scalar one -- what it saves is issue slots: the head's backward reduce ran ~215 vector
+// instructions per 8-channel vector (75 of them v_mov shuffling values into and out of the pairs the SLP vectoriser formed), i.e. it was
+// bound by VALU issue (~90 us of pure issue at B = 32 x 256 x 256), not by its 302 MB of traffic.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+template <typename T>
+__device__ __forceinline__ f2 round_to2(f2 v) {          // round_to<T> of both elements (one v_cvt_pk_* where the type has one)
+  if constexpr (sizeof(T) == 4) return v;
+  else if constexpr (__is_same(T, bf16)) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    asm("" : "+v"(v));
+    f2 r = __builtin_convertvector(__builtin_convertvector(v, b2), f2);
+    asm("" : "+v"(r));
+    return r;
+  } else return f2{round_to<T>(v[0]), round_to<T>(v[1])};
+}
+// the eight values of a 16-byte vector as four pairs
+template <typename T>
+struct P4 {
+  f2 p[4];
+  __device__ __forceinline__ static P4 load(const T* ptr) {
+    const F8 v = load8<T>(ptr);
+    P4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.p[i] = f2{v.v[2 * i], v.v[2 * i + 1]};
+    return r;
+  }
+};
+
 // coefficients of 8 channels starting at c0 (zeros beyond C)
 struct Coef8 {
   float sc[8], sh[8], mu[8], is[8];
@@ -382,61 +414,119 @@ __global__ __launch_bounds__(256, MAU_HEAD_WAVES) void head_bn_bwd_reduce_kernel
   float* row = head_slab + (size_t)blockIdx.x * rowlen;
   Coef8 k;
   k.load(scale, shift, mean, invstd, c0, C);
-  float s1[8], s2[8], dwp[MC][8], dbp[MC], wr[MC][8];
+  // (pairs of channels: see "packed fp32" at the top of the file -- same operations, same order, same bits as the scalar spelling)
+  f2 sc2[4], sh2[4], mu2[4], is2[4], s1p[4], s2p[4], dwq[MC][4], wq[MC][4];
+  float dbp[MC];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    sc2[i] = f2{k.sc[2 * i], k.sc[2 * i + 1]};
+    sh2[i] = f2{k.sh[2 * i], k.sh[2 * i + 1]};
+    mu2[i] = f2{k.mu[2 * i], k.mu[2 * i + 1]};
+    is2[i] = f2{k.is[2 * i], k.is[2 * i + 1]};
+    s1p[i] = s2p[i] = f2{0.f, 0.f};
+  }
 #pragma unroll
   for (int o = 0; o < MC; ++o) {
     dbp[o] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      dwp[o][j] = 0.f;
-      wr[o][j] = o < Co ? coef(w + o * C, c0 + j, C) : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      dwq[o][i] = f2{0.f, 0.f};
+      wq[o][i] = f2{o < Co ? coef(w + o * C, c0 + 2 * i, C) : 0.f, o < Co ? coef(w + o * C, c0 + 2 * i + 1, C) : 0.f};
     }
   }
-  auto one = [&](const F8& v, const float* dz) {
+  auto one = [&](const P4<T>& v, const float* dz) {
 #pragma unroll
     for (int o = 0; o < MC; ++o) dbp[o] += dz[o];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float act = fmaf(v.v[j], k.sc[j], k.sh[j]);
-      const float a = round_to<T>(fmaxf(act, 0.f));                 // the activation bn_relu_apply stored
-      float s = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const f2 act = pk_fma(v.p[i], sc2[i], sh2[i]);
+      const f2 a = round_to2<T>(f2{fmaxf(act[0], 0.f), fmaxf(act[1], 0.f)});       // the activation bn_relu_apply stored
+      f2 s = f2{0.f, 0.f};
 #pragma unroll
       for (int o = 0; o < MC; ++o)
         if (EX || o < Co) {
-          s = fmaf(dz[o], wr[o][j], s);
-          dwp[o][j] = fmaf(dz[o], a, dwp[o][j]);
+          s = pk_fma(splat(dz[o]), wq[o][i], s);
+          dwq[o][i] = pk_fma(splat(dz[o]), a, dwq[o][i]);
         }
-      const float da = round_to<T>(s);                              // the gradient head_bwd stored
-      const float dzb = act > 0.f ? da : 0.f;
-      s1[j] += dzb;
-      s2[j] = fmaf(dzb, (v.v[j] - k.mu[j]) * k.is[j], s2[j]);
+      const f2 da = round_to2<T>(s);                                             // the gradient head_bwd stored
+      const f2 dzb = f2{act[0] > 0.f ? da[0] : 0.f, act[1] > 0.f ? da[1] : 0.f};
+      s1p[i] += dzb;
+      s2p[i] = pk_fma(dzb, (v.p[i] - mu2[i]) * is2[i], s2p[i]);
     }
+  };
+  // The loop is a software pipeline of depth two: the loads of the NEXT pixel pair (16 bytes of y + the head's out / dout words, per
+  // pixel) are issued before the current pair is evaluated.  With the loads at the top of each iteration a wave had 2 KB of y in
+  // flight and three waves per SIMD (LDS, registers) made 24 KB per CU -- 6 MB on the chip against the ~11 MB that 5.5 TB/s at ~2 us
+  // of latency need: the kernel ran at 2.3 TB/s of its traffic.  Only pairs that lie inside the block are prefetched (no clamps: the
+  // addresses stay linear in the loop counter); what is left at the end of the last block runs unpipelined.
+  struct Raw {
+    P4<T> v;
+    float t, g[MC];
+  };
+  auto fetch = [&](int64_t pa, int na, int qa, Raw& r) {
+    r.v = P4<T>::load(y + pa * ldy + c0);
+    const size_t base = (size_t)na * Co * HW + qa;
+    r.t = out[base];
+#pragma unroll
+    for (int o = 0; o < MC; ++o) r.g[o] = dout[base + (size_t)((EX || o < Co) ? o : Co - 1) * HW];
+  };
+  auto eval = [&](const Raw& r) {                        // head_dz's arithmetic on the fetched words
+    float dz[MC];
+    const float f0 = tanh0 ? fmaf(-r.t, r.t, 1.f) : 1.f;
+#pragma unroll
+    for (int o = 0; o < MC; ++o) dz[o] = (EX || o < Co) ? (o == 0 ? r.g[o] * f0 : r.g[o]) : 0.f;
+    one(r.v, dz);
   };
   if (c0 < C8) {
     int n = (int)((p0 + ps) / HW);
     int q = (int)((p0 + ps) - (int64_t)n * HW);
     int64_t p = p0 + ps;
-    for (; p + 32 < p1; p += 64) {                       // two pixels per iteration: their loads are issued together (four: slower,
-      int n2 = n, q2 = q;                                //  the 2 x (dW, db) accumulators leave no room for four vectors in flight)
+    if (p + 32 < p1) {
+      Raw a, b;
+      int n2 = n, q2 = q;
       pos_step32(n2, q2, HW);
-      float dza[MC], dzb2[MC];
-      const F8 va = load8<T>(y + p * ldy + c0), vb = load8<T>(y + (p + 32) * ldy + c0);
-      head_dz<MC, EX>(out, dout, tanh0, Co, HW, n, q, dza);
-      head_dz<MC, EX>(out, dout, tanh0, Co, HW, n2, q2, dzb2);
-      one(va, dza);
-      one(vb, dzb2);
+      fetch(p, n, q, a);
+      fetch(p + 32, n2, q2, b);
       n = n2;
       q = q2;
+      pos_step32(n, q, HW);                              // (n, q) = position of pixel p + 64
+      for (; p + 96 < p1; p += 64) {                     // invariant: (a, b) = pixels (p, p + 32), fetched; the next pair lies inside the block
+        Raw na, nb;
+        n2 = n;
+        q2 = q;
+        pos_step32(n2, q2, HW);
+        fetch(p + 64, n, q, na);
+        fetch(p + 96, n2, q2, nb);
+        eval(a);
+        eval(b);
+        a = na;
+        b = nb;
+        n = n2;
+        q = q2;
+        pos_step32(n, q, HW);
+      }
+      eval(a);
+      eval(b);
+      p += 64;
+    }
+    for (; p < p1; p += 32) {                            // (at most one pixel is left)
+      Raw r;
+      fetch(p, n, q, r);
+      eval(r);
       pos_step32(n, q, HW);
     }
-    for (; p < p1; p += 32) {
-      float dz[MC];
-      const F8 v = load8<T>(y + p * ldy + c0);
-      head_dz<MC, EX>(out, dout, tanh0, Co, HW, n, q, dz);
-      one(v, dz);
-      pos_step32(n, q, HW);
+  }
+  float s1[8], s2[8], dwp[MC][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s1[2 * i] = s1p[i][0];
+    s1[2 * i + 1] = s1p[i][1];
+    s2[2 * i] = s2p[i][0];
+    s2[2 * i + 1] = s2p[i][1];
+#pragma unroll
+    for (int o = 0; o < MC; ++o) {
+      dwp[o][2 * i] = dwq[o][i][0];
+      dwp[o][2 * i + 1] = dwq[o][i][1];
     }
   }
   // head partials (head_bwd_kernel's LDS join; one 64-channel group)

@@ -1097,9 +1097,6 @@ static int launch(const ConvP& p, hipStream_t st) {
 struct Variant {
   int th, nw, bn;                  // tile rows, waves per workgroup, output channels per workgroup   ((32, 4, 64) = <64,4,4>; (32, 8, 64) = <64,2,8>; (32, 8, 128) = <128,4,8>)
 };
-#ifndef MAU_CONV_L0_DEFAULT
-#define MAU_CONV_L0_DEFAULT 1
-#endif
 static inline Variant pick_variant(int CoutPad, int N, int H, int W, int Cin) {
   static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 64;
   const bool wide = CoutPad % 128 == 0;
@@ -1135,9 +1132,13 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W, int Cin) {
   // tile (<64,4,4>, the same 128-pixel wave strips and 16x16x32 stage-pair loop).  At K = 64..192 an item is 2-6 stage pairs and ends
   // in an epilogue that moves 128 KB per CU through the store path with the matrix pipes idle (all eight waves of the one resident
   // workgroup are in it together); two workgroups drift apart, one's epilogue runs beside the other's multiply loop.  Costs: the weight
-  // slab is fetched by both (L2 hits; 74 instead of 55 DMA bytes per pixel).  MAU_CONV_L0: 1 = on, 0 = off (A/B).
-  static const int l0 = getenv("MAU_CONV_L0") ? atoi(getenv("MAU_CONV_L0")) : MAU_CONV_L0_DEFAULT;
-  if (l0 && !wide && best.th == 64 && th_max >= 64) best = {32, 4, 64};
+  // slab is fetched by both (L2 hits; 74 instead of 55 DMA bytes per pixel) -- which is why the choice depends on K (round 6,
+  // profiles/r6/level0_tile_form_by_k.txt, same call, alternating): K = 64: <64,4,4> 3-5 % faster; K = 192: equal; K = 208..400 (the
+  // U-Net++'s full-resolution nodes): the one 8-wave workgroup on the 64 x 16 tile <64,4,8> 3-5 % faster forward -- the epilogue is a
+  // seventh to a thirteenth of such an item and the DMA bytes are what is left.  Both forms write the same statistics slab geometry
+  // (conv_bf16_v2_num_pixel_tiles does not know Cin).  Cin = 0: unknown (the slab-geometry query).
+  static const int l0 = getenv("MAU_CONV_L0") ? atoi(getenv("MAU_CONV_L0")) : -1;      // test hook: 0 / 1 force <64,4,8> / <64,4,4> (both forms stay under the exact big-tile tests)
+  if (!wide && best.th == 64 && th_max >= 64 && (l0 < 0 ? Cin <= 192 : l0 != 0)) best = {32, 4, 64};
   return best;
 }
 }  // namespace v2
