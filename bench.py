@@ -131,7 +131,7 @@ def cpu_baseline(iters=5, warmup=2, b32=False):
     train step (fwd + MSE + bwd + AdamW), train-mode forward and eval-mode forward timed separately.
     SURVEY 8(d) also names B = 32: ONE iteration of the full-batch step costs about a minute of host time, so the default run
     does not repeat it -- ``--cpu-baseline-b32`` times that one iteration (after one untimed B = 2 step that has paged the
-    operators in), and the default line quotes the committed record of it (profiles/r5/cpu_baseline_b32.json) beside the B = 2
+    operators in), and the default line quotes the committed record of it (profiles/r<N>/cpu_baseline_b32.json, newest round) beside the B = 2
     sample, saying which is which."""
     from oracle import unet_ref as R
     torch.manual_seed(0)
@@ -171,12 +171,30 @@ def cpu_baseline(iters=5, warmup=2, b32=False):
                                     "sample": "ONE iteration of the B=32 train step (the bench's own batch), after the B=2 iterations above"}
     else:
         try:
-            with open(os.path.join(ROOT, "profiles", "r5", "cpu_baseline_b32.json")) as f:
+            with open(newest_record("cpu_baseline_b32.json")) as f:
                 rec["b32_recorded"] = dict(json.load(f), note="NOT of this run: the committed one-iteration B=32 record (python bench.py --cpu-baseline-b32); "
                                                               "this run timed the B=2 sample only")
-        except (OSError, ValueError):
+        except (OSError, ValueError, TypeError):
             pass
     return rec
+
+
+def record_rounds():
+    """profiles/r<N> directories, newest round first (the committed records a line may quote -- always labelled as such)."""
+    try:
+        ds = [d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit()]
+    except OSError:
+        return []
+    return sorted(ds, key=lambda d: -int(d[1:]))
+
+
+def newest_record(name):
+    """path of the newest round's profiles/r<N>/<name> that exists (None if no round has one)"""
+    for rnd in record_rounds():
+        p = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(p):
+            return p
+    return None
 
 
 STAGE_TAG = "[mau-bench-stage]"
@@ -718,7 +736,7 @@ def main():
         with open(_lib.LIB_PATH, "rb") as f:
             lib_sha = hashlib.sha256(f.read()).hexdigest()
         src = "no PMC record of this workload under profiles/"
-        for rnd in ("r5", "r4", "r3", "r2"):
+        for rnd in record_rounds():
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
                     cand = json.load(f)[wkey]
@@ -765,7 +783,7 @@ def main():
         """N > 1, before this run's own per-kernel event pass has completed: the dominant kernel's figures of the committed
         one-GPU record of the same workload (the kernel does not know how many ranks there are) -- replaced by the live
         figures in the final line; this one only survives if the event pass hangs."""
-        for rnd in ("r5", "r4"):
+        for rnd in record_rounds()[:2]:
             for name in ("bench_default.json", f"bench_{wkey}.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", rnd, name)) as f:

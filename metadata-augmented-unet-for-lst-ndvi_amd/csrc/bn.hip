@@ -715,13 +715,6 @@ int mau_bn_relu_bwd_apply(const void* da, int ldda, const void* y, int ldy, cons
   // up to 64 pixels per thread and as few as 256 workgroups: this kernel's per-channel set-up (6 coefficient vectors,
   // fp64 means) is what the mid-size layers were paying for (C=256: 61 -> 36 us, scripts/elementwise_bench.py)
   const int pixb = pixvec_pixels_per_block(C8 / 8, npix, 64, 256);
-  static const bool nt = getenv("MAU_BN_NT") ? atoi(getenv("MAU_BN_NT")) != 0 : false;
-  if (nt) {
-    MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((bn_relu_bwd_apply_kernel<T, true>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, sums,
-                                         count > 0 ? 1.0 / count : 0.0, (T*)dy, lddy, npix, C, C8, pixb));
-    return check_launch("bn_relu_bwd_apply_kernel");
-  }
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((bn_relu_bwd_apply_kernel<T, false>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream,
                                                (const T*)da, ldda, (const T*)y, ldy, scale, shift, mean, invstd, sums,
                                                count > 0 ? 1.0 / count : 0.0, (T*)dy, lddy, npix, C, C8, pixb));

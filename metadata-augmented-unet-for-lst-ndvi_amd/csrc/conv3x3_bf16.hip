@@ -1037,8 +1037,7 @@ static int launch(const ConvP& p, hipStream_t st) {
   const bool emb_ok = p.E == 0 || (p.emb_lp != nullptr && p.E % KC == 0 && (p.C0 + p.C1) % KC == 0 && p.ldx % KC == 0);
   const bool one = p.C1 == 0 && p.ldx % KC == 0 && round_up(p.C0, KC) <= p.ldx;
   const bool two = p.C1 > 0 && p.C0 % KC == 0 && p.C0 <= p.ldx && round_up(p.C1, KC) <= p.ldx1;
-  static const bool no_buf = getenv("MAU_CONV_GENERAL_LOADER") != nullptr;      // A/B: the 64-bit-address loader for every layer
-  q.fast = !no_buf && emb_ok && (one || two) && px * p.ldx * 2 < (1ll << 31) && px * p.ldx1 * 2 < (1ll << 31) ? 1 : 0;
+  q.fast = emb_ok && (one || two) && px * p.ldx * 2 < (1ll << 31) && px * p.ldx1 * 2 < (1ll << 31) ? 1 : 0;
   if ((long long)q.nChunks * 9 * p.CoutPad * KC * 2 >= (1ll << 31)) {
     set_error("conv3x3_fwd: packed weights beyond 2 GiB");
     return MAU_ERR_ARG;
@@ -1057,13 +1056,12 @@ static int launch(const ConvP& p, hipStream_t st) {
   int grid = launch_cus() / ds.xcds * ds.xcds * per_cu;      // a multiple of the XCD count, like nItems: a workgroup stays on its XCD's slice
   if (grid > nItems) grid = nItems;
   // the 16x16x32 loop walks stages in pairs: big-tile variants, buffer-addressed loader, an even number of stages
-  // (MAU_CONV_M16=0: the 32x32x16 loop everywhere, for same-box A/B timing)
+  // (MAU_CONV_M16=0: the 32x32x16 loop everywhere -- the exact big-tile tests run both loops on the production tilings)
   static const bool m16 = getenv("MAU_CONV_M16") == nullptr || atoi(getenv("MAU_CONV_M16")) != 0;
   bool done = false;
   if constexpr (MT == 4) {
     if (m16 && q.fast && q.nChunks % 2 == 0) {
-      static const bool no_one = getenv("MAU_CONV_ONE") != nullptr && atoi(getenv("MAU_CONV_ONE")) == 0;      // A/B switch
-      if (p.C1 == 0 && p.E == 0 && !no_one)
+      if (p.C1 == 0 && p.E == 0)
         MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
       else
         MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, true, true>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
@@ -1098,14 +1096,12 @@ struct Variant {
   int th, nw, bn;                  // tile rows, waves per workgroup, output channels per workgroup   ((32, 4, 64) = <64,4,4>; (32, 8, 64) = <64,2,8>; (32, 8, 128) = <128,4,8>)
 };
 static inline Variant pick_variant(int CoutPad, int N, int H, int W, int Cin) {
-  static const int th_max = getenv("MAU_CONV_TH_MAX") ? atoi(getenv("MAU_CONV_TH_MAX")) : 64;
   const bool wide = CoutPad % 128 == 0;
   // A 128-multiple layer whose 16-row items would keep fewer than half of the CUs busy (single-tile inference at the deep levels:
   // 512 x 512, B = 1 gives 32 items of <128,2,8> at 32 x 32 pixels) runs on the 64-channel workgroups instead: twice the items of
   // half the work, on twice the CUs (B = 1 conv4_0.conv2: 86 -> 45 us).  The packed weights are laid out per 64-channel block, so
-  // both widths read the same packs.  MAU_CONV_NARROW=0 switches the rule off (A/B).
-  static const bool narrow = getenv("MAU_CONV_NARROW") == nullptr || atoi(getenv("MAU_CONV_NARROW")) != 0;
-  if (wide && narrow) {
+  // both widths read the same packs.
+  if (wide) {
     const long tiles16 = (long)N * ceil_div(H, 16) * ceil_div(W, TW);
     // (... and 8-row tiles <64,1,4> while even those items are fewer than half of the CUs: the chain of one wave halves again)
     if (tiles16 * (CoutPad / 64) * 2 <= device_shape().cus) return {8, 4, 64};        // <64,1,4>
@@ -1115,7 +1111,7 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W, int Cin) {
   Variant best = {16, wide ? 8 : 4, wide ? 128 : 64};
   double best_score = -1.0;
   // 64-row tiles exist for the 64-wide variant only (<64,4,8>: the per-MFMA LDS-read and DMA ratios of <128,4,8>)
-  for (int th = 16; th <= (wide ? 32 : 64) && th <= th_max; th *= 2) {
+  for (int th = 16; th <= (wide ? 32 : 64); th *= 2) {
     const int nw = wide || th > 16 ? 8 : 4;
     const int slots = device_shape().cus * (nw == 4 ? 2 : 1);      // <64,2,4> runs two workgroups per CU
     const long tilesY = ceil_div(H, th), tilesX = ceil_div(W, TW);
@@ -1138,7 +1134,7 @@ static inline Variant pick_variant(int CoutPad, int N, int H, int W, int Cin) {
   // seventh to a thirteenth of such an item and the DMA bytes are what is left.  Both forms write the same statistics slab geometry
   // (conv_bf16_v2_num_pixel_tiles does not know Cin).  Cin = 0: unknown (the slab-geometry query).
   static const int l0 = getenv("MAU_CONV_L0") ? atoi(getenv("MAU_CONV_L0")) : -1;      // test hook: 0 / 1 force <64,4,8> / <64,4,4> (both forms stay under the exact big-tile tests)
-  if (!wide && best.th == 64 && th_max >= 64 && (l0 < 0 ? Cin <= 192 : l0 != 0)) best = {32, 4, 64};
+  if (!wide && best.th == 64 && (l0 < 0 ? Cin <= 192 : l0 != 0)) best = {32, 4, 64};
   return best;
 }
 }  // namespace v2

@@ -353,11 +353,8 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
     }
 }
 
-// MAU_WGRAD_XCD=0: the id = split + nsplit * tile order and unconstrained split counts (same-process A/B; read per call)
-static inline bool wgrad_xcd_order() {
-  const char* e = getenv("MAU_WGRAD_XCD");
-  return e == nullptr || atoi(e) != 0;
-}
+// (the XCD-contiguous work-item order and whole split counts per XCD; round 3 A/B'd it against id = split + nsplit * tile: kept)
+static inline bool wgrad_xcd_order() { return true; }
 
 template <int BCO, int KG, bool F16, int NS>
 static int launch(const WgradP& p, int nsplit, hipStream_t st) {
@@ -427,16 +424,14 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   // (profiles/r5/layer_traffic.txt of the first records), for 4 % of one launch that the step does not see; it stays at s = 8.
   int best = 1;
   double best_cost = 1e300;
-  const long cus = launch_cus();                    // the device's CUs, or the calling thread's budget (mau_set_cu_budget)
+  const long cus = launch_cus();
   const int xcds = wg2::wgrad_xcd_order() ? device_shape().xcds : 1;
   const double ov = v.k16 ? 16.0 : 10.0;
-  static const bool r4_rule = getenv("MAU_WGRAD_SPLIT_MODEL") != nullptr && atoi(getenv("MAU_WGRAD_SPLIT_MODEL")) == 0;    // A/B: round 4's rule
   for (int s = 1; s <= smax; ++s) {                // s = workgroups along the split axis = partial slabs
     if (s >= xcds && s % xcds != 0) continue;      // whole splits per XCD (see the kernel's work-item order)
     const long blocks = (long)outTiles * s;
     const long rounds = (blocks + cus - 1) / cus;
-    const double cost = r4_rule ? 0.0015 * s - (double)blocks / (double)(rounds * cus)      // (grid fill first, then fewer splits)
-                                : (double)rounds * ((double)ceil_div(nTiles, s) + ov) * ((xcds > 1 && s % xcds != 0 && outTiles >= xcds) ? 1.10 : 1.0);
+    const double cost = (double)rounds * ((double)ceil_div(nTiles, s) + ov) * ((xcds > 1 && s % xcds != 0 && outTiles >= xcds) ? 1.10 : 1.0);
     if (cost < best_cost - 1e-9 * (best_cost < 0 ? -best_cost : best_cost)) {
       best_cost = cost;
       best = s;

@@ -790,9 +790,7 @@ int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst,
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldsrc % 8 == 0 && lddst % 8 == 0 && choff % 8 == 0 && ldsrc >= C8 && lddst >= choff + C8, "resize_bilinear_fwd: bad ld/choff");
   MAU_REQUIRE(H <= 65535 && N <= 65535, "resize_bilinear_fwd: H and N must fit a grid dimension");
-  static const bool no_cell = getenv("MAU_RESIZE_NO_CELL") != nullptr;              // (A/B timing)
-  static const bool no_rows = getenv("MAU_RESIZE_NO_ROWS") != nullptr;
-  if (resize_rows_ok(h, w, H, W) && !no_cell && !no_rows) {   // upsampling by <= ~2: a column of source cells per thread
+  if (resize_rows_ok(h, w, H, W)) {                    // upsampling by <= ~2: a column of source cells per thread
     const int xb = ceil_div(w * (C8 / 8), 256);
     int RY = 8;
     while (RY > 1 && (int64_t)xb * ceil_div(h, RY) * N < 1024) RY >>= 1;
@@ -801,7 +799,7 @@ int mau_resize_bilinear_fwd(const void* src, int ldsrc, int h, int w, void* dst,
                                          H, W, C8, (const float*)nullptr, (const float*)nullptr, C, RY));
     return check_launch("resize_rows_kernel");
   }
-  if (h <= H && w <= W && h <= 65535 && !no_cell) {                                // upsampling: one thread per source cell
+  if (h <= H && w <= W && h <= 65535) {                // any other upsampling: one thread per source cell
     dim3 gridc(ceil_div(w * (C8 / 8), 256), h, N);
     MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((resize_fwd_cell_kernel<T, false>), gridc, dim3(256), 0, (hipStream_t)stream, (const T*)src, ldsrc, h, w, (T*)dst, lddst, choff, H, W, C8,
                                          (const float*)nullptr, (const float*)nullptr, C));
@@ -818,8 +816,7 @@ int mau_resize_bilinear_bn_fwd(const void* y, int ldy, int h, int w, const float
   MAU_REQUIRE(h <= H && w <= W && h <= 65535 && N <= 65535, "resize_bilinear_bn_fwd: an upsampling (h <= H, w <= W), h and N within a grid dimension");
   const int C8 = round_up(C, 8);
   MAU_REQUIRE(ldy % 8 == 0 && lddst % 8 == 0 && choff % 8 == 0 && ldy >= C8 && lddst >= choff + C8, "resize_bilinear_bn_fwd: bad ld/choff");
-  static const bool no_rows = getenv("MAU_RESIZE_BN_CELL") != nullptr;             // (A/B timing: the one-cell-per-thread form)
-  if (!no_rows && resize_rows_ok(h, w, H, W)) {                                    // upsampling by <= ~2: a column of source cells per thread
+  if (resize_rows_ok(h, w, H, W)) {                    // upsampling by <= ~2: a column of source cells per thread
     const int xb = ceil_div(w * (C8 / 8), 256);
     int RY = 8;
     while (RY > 1 && (int64_t)xb * ceil_div(h, RY) * N < 1024) RY >>= 1;

@@ -211,7 +211,7 @@ def pack_conv_weights(w: torch.Tensor, code: int, forward: bool = True, dgrad: b
     if cache is not None and cache[0] == key and (cache[1] is not None or not forward) and (cache[2] is not None or not dgrad):
         return (cache[1] if forward else None), (cache[2] if dgrad else None)
     group = getattr(w, "_mau_group", None)
-    if group is not None and os.environ.get("MAU_PACK_MULTI", "1") != "0":
+    if group is not None and _PACK_MULTI:
         group.ensure(code)
         cache = w._mau_pack
         return (cache[1] if forward else None), (cache[2] if dgrad else None)
@@ -328,11 +328,17 @@ def _all_reduce_(t: torch.Tensor, st: BNState):
 # (a 227-register weight-gradient wave leaves no room for a BatchNorm wave on its SIMD: the kernels share the chip by CU, not by
 # issue slot).  The eager figure depends on the host: on a box with a slow / busy CPU the extra stream bookkeeping made the eager
 # step SLOWER (17-18 vs 14-16 ms); the captured step does not care.  Default "2"; "0" = one stream.
-_OVERLAP_WGRAD = int(os.environ.get("MAU_OVERLAP_WGRAD", "2") or 0)
-_FUSED_REDUCE = os.environ.get("MAU_FUSED_REDUCE", "1") != "0"        # single-launch slab reductions (A/B switch; bit-identical)
-_FUSED_BN = os.environ.get("MAU_FUSED_BN", "1") != "0"                # BatchNorm passes fused with pool / head / upsample (A/B switch; bit-identical)
-_FUSED_UP = os.environ.get("MAU_FUSED_UP", "1") != "0"                # (the upsample member of the above, separately switchable)
-_FIRST_WGRAD = os.environ.get("MAU_FIRST_WGRAD", "1") != "0"          # the first layer's weight gradient on its own kernel (A/B switch)
+# Test hooks (plain module attributes; the tests flip them with monkeypatch to compare a fused path with the launches it replaces, bit for
+# bit).  They were environment switches while the A/B measurements ran (EXPERIMENTS.md); every one is decided, none is read from the
+# environment any more.
+# (MAU_OVERLAP_WGRAD is the one environment variable left here: 0 = everything on one stream, the form a per-kernel profile needs --
+#  scripts/profile.sh, scripts/step_trace.py)
+_OVERLAP_WGRAD = int(os.environ.get("MAU_OVERLAP_WGRAD", "2") or 0)      # weight gradients on a side stream: 0 = off, 1 = joined per layer, 2 = ONE join when the backward pass ends
+_FUSED_REDUCE = True        # single-launch slab reductions (tickets)
+_FUSED_BN = True            # BatchNorm passes fused with pool / head / upsample
+_FUSED_UP = True            # (the upsample member of the above, separately switchable)
+_PACK_MULTI = True          # one multi-tensor weight-pack launch per optimizer step (functional.PackGroup)
+_FIRST_WGRAD = True         # the first layer's weight gradient on its own kernel (csrc/conv3x3_first.hip)
 _SIDE_STREAMS = {}
 
 
@@ -354,8 +360,8 @@ def _join_side_when_backward_ends(dev):
     torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
-# launch order inside ConvBNReLU.backward: None = the network's choice (BNState.dgrad_first), "0" / "1" = forced (same-call A/B)
-_DGRAD_FIRST = os.environ.get("MAU_BWD_DGRAD_FIRST")
+# launch order inside ConvBNReLU.backward: None = the network's choice (BNState.dgrad_first), "0" / "1" = forced (test hook)
+_DGRAD_FIRST = None
 
 
 def _conv_fwd(x, x1, st, emb, emb_ws, E, wpk, bias, post, y, Cout, slab, code, N, H, W, stream):
@@ -967,8 +973,8 @@ class EmbFold(torch.autograd.Function):
 
 
 _EMB_IDENTITY = {}
-_EMB_FOLD = os.environ.get("MAU_EMB_FOLD", "1") != "0"        # the broadcast embedding folded into roundup(N, 16) indicator channels (training)
-_EMB_FOLD_MIN_WORK = int(os.environ.get("MAU_EMB_FOLD_MIN_WORK", str(1 << 20)))      # batch x pixels from which folding pays
+_EMB_FOLD = True            # the broadcast embedding folded into roundup(N, 16) indicator channels (training; test hook)
+_EMB_FOLD_MIN_WORK = 1 << 20      # batch x pixels from which folding pays (test hook)
 
 
 def emb_identity(N: int, Ep: int, dev) -> torch.Tensor:

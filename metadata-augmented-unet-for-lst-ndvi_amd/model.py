@@ -127,6 +127,13 @@ class VGGBlock(nn.Module):
         return self._half(x, None, self.conv2, self.bn2, None, pool, out_view, head, head_act, up_to)
 
 
+# Test hooks (module attributes, flipped by the tests with monkeypatch; decided A/B switches of earlier rounds, no longer environment variables)
+_OVERLAP_LSTM = True          # the TemporalEncoder's recurrence on a side stream beside the first encoder blocks (training)
+_OVERLAP_LSTM_GRAPH = True    # ... also inside a captured step (a second branch of the hipGraph)
+_CONV_FIRST = True            # conv0_0.conv1 on the first-layer kernel (reads the fp32 NCHW input and the fp32 weights directly)
+_VIRTUAL_CONCAT = True        # decoder concatenations as loader sources / U-Net++ row buffers instead of materialised tensors
+_FANOUT = True                # U-Net++: one alias per reader of a row slot, the readers' gradients summed by one kernel
+
 _SIDE_STREAMS = {}
 _OVERLAP_OFF = [0]          # > 0: inside train_graph.GraphedTrainStep (its warm-up steps and the capture run on ONE stream)
 
@@ -148,11 +155,11 @@ def _overlap_lstm(t: torch.Tensor, training: bool) -> bool:
     (forward) and -- autograd replays a node on its forward stream -- beside the encoder's backward (also under a process
     group: dist.GradSync makes a bucket's launching stream wait for every stream that produced one of its gradients).
     Not in eval (hipGraph sessions, latency)."""
-    if not (training and t.is_cuda) or _OVERLAP_OFF[0] > 0 or os.environ.get("MAU_OVERLAP_LSTM", "1") == "0":
+    if not (training and t.is_cuda) or _OVERLAP_OFF[0] > 0 or not _OVERLAP_LSTM:
         return False
     # inside a captured train step the side stream forks from / joins the capturing stream (wait_stream both ways): the
     # overlap becomes two branches of the hipGraph (MAU_OVERLAP_LSTM_GRAPH=0: one branch)
-    return not torch.cuda.is_current_stream_capturing() or os.environ.get("MAU_OVERLAP_LSTM_GRAPH", "1") != "0"
+    return not torch.cuda.is_current_stream_capturing() or _OVERLAP_LSTM_GRAPH
 
 
 class TemporalEncoder(nn.Module):
@@ -272,7 +279,7 @@ class _NetBase(nn.Module):
         # 16-bit modes, at most 8 input channels (BASELINE configs: 6), no gradient w.r.t. the input: the first convolution reads the
         # tensor as it is (mau_conv3x3_first_fwd) -- no NCHW -> NHWC layout kernel, no packed copy of its weights.  MAU_CONV_FIRST=0: A/B.
         if (self._rt.dtype != torch.float32 and maps.dim() == 4 and maps.shape[1] <= F_.lib.mau_conv3x3_first_max_channels()
-                and not (maps.requires_grad and torch.is_grad_enabled()) and os.environ.get("MAU_CONV_FIRST", "1") != "0"):
+                and not (maps.requires_grad and torch.is_grad_enabled()) and _CONV_FIRST):
             F_._require_cuda(maps, "UrbanPredictor.forward(maps)")
             return Act(maps, maps.shape[1], nchw=True)
         return Act(F_.ToNHWC.apply(maps, self._rt.dtype), maps.shape[1])
@@ -285,7 +292,7 @@ class _NetBase(nn.Module):
 
     def _fusable(self, skip: Act) -> bool:
         """Virtual concat needs a 16-bit activation dtype and a first tensor that ends on a 16-channel stage boundary."""
-        return self._rt.dtype != torch.float32 and skip.C % 16 == 0 and os.environ.get("MAU_VIRTUAL_CONCAT", "1") != "0"
+        return self._rt.dtype != torch.float32 and skip.C % 16 == 0 and _VIRTUAL_CONCAT
 
     def _pool(self, a: Act) -> Act:
         return Act(F_.MaxPool2x2.apply(a.t, a.C), a.C)
@@ -493,7 +500,7 @@ class UrbanPredictor_unetpp(_NetBase):
         nb0 = self.conv0_0.conv2.out_channels
         # The buffers are written by raw kernels through ``BNState.out_view`` and read through views: no torch in-place op may
         # ever touch them (it would bump the version counter autograd checks for the saved slots).
-        use_rows = self._rt.dtype != torch.float32 and nb0 % 64 == 0 and os.environ.get("MAU_VIRTUAL_CONCAT", "1") != "0"
+        use_rows = self._rt.dtype != torch.float32 and nb0 % 64 == 0 and _VIRTUAL_CONCAT
         N, H, W = x.N, x.H, x.W
         hs, ws = [H], [W]
         for _ in range(3):
@@ -511,7 +518,7 @@ class UrbanPredictor_unetpp(_NetBase):
         # Every node but the last of a row is read several times -- by the later nodes of its row and by the node above it
         # (src/model.py:136-177).  Each reader gets its own alias (functional.Fanout): the readers' gradients are then summed by one
         # kernel in the alias node's backward instead of by autograd's generic strided adds (16 launches, 0.85 ms of a B=16 step).
-        fan_on = self.training and torch.is_grad_enabled() and os.environ.get("MAU_FANOUT", "1") != "0"
+        fan_on = self.training and torch.is_grad_enabled() and _FANOUT
         ds = 1 if self.deep_supervision else 0            # (the deep-supervision heads read x^{0,1..3} once more)
 
         class Fan:

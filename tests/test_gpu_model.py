@@ -362,7 +362,7 @@ def test_virtual_concat_and_fused_pool_are_bitwise_equal_to_materialised(mau, mo
     tgt = torch.randn(2, 2, 48, 40, generator=g).cuda()
     res = []
     for virt in ("1", "0"):
-        monkeypatch.setenv("MAU_VIRTUAL_CONCAT", virt)
+        monkeypatch.setattr(__import__("mau_amd.model", fromlist=["x"]), "_VIRTUAL_CONCAT", virt == "1")
         torch.manual_seed(30)
         net = mau.UrbanPredictor(model_type, 6, 10, 16, 4, 16, 24, 2, base_filters=base, **flags).cuda().set_precision("bf16").train()
         out = net(x, ts, md)
@@ -412,7 +412,7 @@ def test_lstm_side_stream_overlap_is_bitwise_neutral(mau, model_type, monkeypatc
     tgt = torch.randn(3, 2, 64, 64, generator=g).cuda()
     res = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("MAU_OVERLAP_LSTM", flag)
+        monkeypatch.setattr(__import__("mau_amd.model", fromlist=["x"]), "_OVERLAP_LSTM", flag == "1")
         torch.manual_seed(50)
         net = mau.UrbanPredictor(model_type, 6, 828, 16, 4, 16, 96, 2, base_filters=32, temporal_embeddings=True).cuda().set_precision("bf16").train()
         opt = torch.optim.AdamW(net.parameters(), lr=1e-3, fused=True)
@@ -864,7 +864,7 @@ def test_single_launch_reductions_and_multi_pack_are_bit_identical(mau, monkeypa
     res = []
     for fused, multi in ((True, "1"), (False, "0")):
         monkeypatch.setattr(F_, "_FUSED_REDUCE", fused)
-        monkeypatch.setenv("MAU_PACK_MULTI", multi)
+        monkeypatch.setattr(F_, "_PACK_MULTI", multi == "1")
         torch.manual_seed(70)
         net = mau.UrbanPredictor("unet", 6, 10, 16, 4, 16, 24, 2, base_filters=32, temporal_embeddings=False).cuda().set_precision("bf16").train()
         opt = torch.optim.AdamW(net.parameters(), lr=1e-3, fused=True)

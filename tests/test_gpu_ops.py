@@ -811,7 +811,7 @@ def test_first_layer_path_matches_generic_path(prec, monkeypatch):
     tgt = torch.randn(2, 2, 64, 80, generator=g).cuda()
     res = {}
     for first in ("1", "0"):
-        monkeypatch.setenv("MAU_CONV_FIRST", first)
+        monkeypatch.setattr(__import__("mau_amd.model", fromlist=["x"]), "_CONV_FIRST", first == "1")
         torch.manual_seed(3)
         net = mau.UrbanPredictor("unet", 6, 10, 16, 4, 16, 24, 2, base_filters=16, temporal_embeddings=False, metadata_embeddings=True).cuda().set_precision(prec).train()
         out = net(x, ts, md)
