@@ -297,6 +297,7 @@ def supervise_workers(cmds_envs, limits=None, poll=0.2, log=sys.stderr, deadline
         except Exception:
             pass
     time.sleep(0.2)                                   # let the stdout reader threads drain
+    supervise_workers.last_failure = failure          # (what ended the attempt, for the forwarded line: run_supervised)
     return failure is None, "".join(state[0]["out"]) if state else ""
 
 
@@ -446,9 +447,22 @@ def run_supervised(make_attempt, log=sys.stderr, coord=None, budget=None):
             if ln not in lines:
                 print(ln, file=log)
         if lines:                                     # (only the supervisor of worker 0 ever holds one)
+            line = lines[-1]
             if not ok:
+                # the value stands (it was measured and printed before the failure), but the line must SAY that something behind it
+                # failed -- a fault or hang in the per-kernel event pass, the forward-latency pass or the teardown is not a success
                 print("bench.py supervisor: the attempt failed AFTER its timed regions; the result line it had printed stands", file=log, flush=True)
-            print(lines[-1], flush=True)
+                try:
+                    rec = json.loads(line)
+                    rec["attempt_failed_after_timed_regions"] = True
+                    rec["failure"] = str(getattr(supervise_workers, "last_failure", None))
+                    rl = rec.get("roofline")
+                    if isinstance(rl, dict):
+                        rl["source"] = "recorded" if str(rl.get("timing", "")).startswith("NOT of this run") else "live"
+                    line = json.dumps(rec)
+                except ValueError:
+                    pass
+            print(line, flush=True)
             rc = 0
             break
         if ok and leader:                             # (no worker 0 here, or a stand-in that prints nothing)
@@ -884,7 +898,7 @@ def main():
     net.eval()
     with torch.no_grad():
         fwd_eager = per_tile(lambda: net(x, ts, md))
-    fwd = {"fwd_ms_per_tile": round(fwd_eager, 4), "fwd_ms_per_tile_eager_unfrozen": round(fwd_eager, 4), "fwd_ms_per_tile_path": "eager eval forward (no inference session)"}
+    fwd = {"fwd_ms_per_tile": round(fwd_eager, 4), "fwd_ms_per_tile_eager": round(fwd_eager, 4), "fwd_eager_frozen": bool(args.infer), "fwd_ms_per_tile_path": "eager eval forward (no inference session)"}
     if not args.infer and world == 1:
         sess = mau_amd.GraphedInference(net, x, ts, md)             # (freezes the model; net.train() below unfreezes it)
         fwd["fwd_ms_per_tile"] = round(per_tile(lambda: sess(x, ts, md)), 4)

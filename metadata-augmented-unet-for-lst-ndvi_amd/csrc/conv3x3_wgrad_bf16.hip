@@ -415,13 +415,13 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   // slab it writes and the second stage reads back), and the launch runs in ceil(workgroups / CUs) rounds:
   //     cost(s) = rounds(s) * (nTiles / s + OV),     OV = 16 iterations of the 4 x 32 tiling, 10 of the 8 x 16 one
   // (fitted to scripts/wgrad_split_probe.py, profiles/r5/wgrad_split_probe.txt: wgrad + second stage per layer over forced split
-  // counts).  Round 4's rule -- fill whole rounds, prefer fewer splits -- agrees on fifteen of the U-Net's eighteen layers; on the
-  // K-heavy ones (hundreds of (co,ci) tiles before any split) it bought the last points of grid fill with two more rounds of slabs:
-  // 1536->512 at 32^2 s = 8 -> 5 (371 -> 355 us, 226 -> 142 MB of slabs), 768->256 at 64^2 s = 32 -> 8 (363 -> 358 us, 226 -> 57 MB),
-  // 576->1024 at 16^2 s = 7 -> 3 (111 -> 91 us, 149 -> 64 MB).  Ties go to the smaller s (less slab traffic).  A split count that is
-  // not a whole number per XCD runs in the plain work-item order, where every XCD reads every pixel range: charged 10 % -- on
-  // 1536->512 at 32^2 the probe's fastest count (s = 5: 355 us against 371) moved 702 MB through the fabric where s = 8 moves 428
-  // (profiles/r5/layer_traffic.txt of the first records), for 4 % of one launch that the step does not see; it stays at s = 8.
+  // counts).  Round 4's rule -- fill whole rounds, prefer fewer splits -- agrees on sixteen of the U-Net's eighteen layers; TWO change,
+  // both K-heavy layers that had bought the last points of grid fill with more rounds of slabs: 768->256 at 64^2 s = 32 -> 8
+  // (363 -> 358 us, 226 -> 57 MB of slabs) and 576->1024 at 16^2 s = 7 -> 3 (111 -> 91 us, 149 -> 64 MB).  Ties go to the smaller s
+  // (less slab traffic).  A split count that is not a whole number per XCD runs in the plain work-item order, where every XCD reads
+  // every pixel range: such counts are charged 10 % -- which is why 1536->512 at 32^2 STAYS at s = 8: the probe's fastest count there
+  // (s = 5: 355 us against 371) moved 702 MB through the fabric where s = 8 moves 428 (profiles/r5/layer_traffic.txt of the first
+  // records), 4 % of one launch that the step does not see.
   int best = 1;
   double best_cost = 1e300;
   const long cus = launch_cus();

@@ -147,9 +147,12 @@ def test_a_hang_after_the_timed_regions_does_not_cost_the_line(tmp_path, capsys,
     rec = json.loads(lines[0])
     assert len(lines) == 1 and rec["launch"] == "graph" and rec["roofline"] == "recorded"
     assert "made no progress" in log and "stage 'timed'" in log and "stands" in log
+    # ... and the forwarded line SAYS so, machine-readably: the late failure is not reported as a clean success
+    assert rec["attempt_failed_after_timed_regions"] is True and "stage 'timed'" in rec["failure"]
     # the normal case: two lines from the worker, the LAST (complete) one is forwarded
     rc, made, lines, log = _run(tmp_path, capsys, monkeypatch, MAU_FAKE_EARLY_LINE="1")
     assert rc == 0 and len(lines) == 1 and json.loads(lines[0])["roofline"] == "live"
+    assert "attempt_failed_after_timed_regions" not in json.loads(lines[0])
 
 
 def test_every_attempt_hanging_ends_inside_the_budget(tmp_path, capsys, monkeypatch):

@@ -179,6 +179,56 @@ def test_conv3x3_k_group_variants_exact(mau, dt, shape):
     assert torch.equal(got, post if float(post.abs().max()) < lim else post.to(dt).float())
 
 
+def test_conv3x3_k_groups_against_one_group_on_real_data(mau, tmp_path):
+    """the two-K-group form changes the summation order (group 0's stages + group 1's stages), and integer data cannot see
+    that.  Real-valued data, B = 1 conv4_0.conv2 of the 512 x 512 network (1024 -> 1024 at 32 x 32, fp16, inference epilogue): the
+    K-group launch (asserted by ``mau_conv3x3_variant``) against the SAME library with ``MAU_CONV_KG=0`` (a child process: the switch is
+    read once) -- both within fp16 output rounding of the fp32 convolution, and of each other by at most a rounding step or two."""
+    import subprocess
+    import sys
+    from mau_amd import functional as F_
+    from mau_amd._lib import conv3x3_variant
+    N, Cin, Cout, H, W = 1, 1024, 1024, 32, 32
+    dt = torch.float16
+    code = F_.dtype_code(dt)
+    assert conv3x3_variant(code, N, H, W, Cout, Cin)[3] == 2
+    script = tmp_path / "kg_case.py"
+    script.write_text(f"""
+import sys, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import mau_amd
+from mau_amd import functional as F_
+from mau_amd._lib import call
+g = torch.Generator().manual_seed(5)
+x = torch.randn({N}, {H}, {W}, {Cin}, generator=g).cuda().half()
+w = (torch.randn({Cout}, {Cin}, 3, 3, generator=g) * 0.02).cuda()
+b, sc, sh = torch.randn({Cout}, generator=g).cuda(), (torch.rand({Cout}, generator=g) + 0.5).cuda(), torch.randn({Cout}, generator=g).cuda()
+code = F_.dtype_code(torch.float16)
+wf = F_.pack_conv_weights(w, code)[0]
+y = torch.empty(({N}, {H}, {W}, {Cout}), dtype=torch.float16, device="cuda")
+call("mau_conv3x3_fwd", x.data_ptr(), {Cin}, {Cin}, None, None, 0, wf.data_ptr(), b.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr(), {Cout}, {Cout},
+     None, code, {N}, {H}, {W}, torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+ref = torch.relu(sc[None, :, None, None] * torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).float(), w.half().float(), b, padding=1) + sh[None, :, None, None])
+torch.save(dict(y=y.cpu(), ref=ref.permute(0, 2, 3, 1).cpu()), sys.argv[1])
+""")
+    outs = {}
+    for kg in ("1", "0"):
+        f = tmp_path / f"kg{kg}.pt"
+        env = dict(os.environ, MAU_CONV_KG=kg, MAU_QUIET="1")
+        p = subprocess.run([sys.executable, str(script), str(f)], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[kg] = torch.load(f)
+    ref = outs["1"]["ref"]
+    for kg in ("1", "0"):
+        e = float((outs[kg]["y"].float() - ref).abs().max() / ref.abs().max())
+        assert e < 2e-3, (kg, e)                                   # fp16 output rounding (2^-11 relative) + fp32 accumulation-order noise
+    d = (outs["1"]["y"].float() - outs["0"]["y"].float()).abs()
+    frac_equal = float((d == 0).float().mean())
+    print(f"K groups vs one group: {frac_equal:.4f} of the outputs bit-equal, max difference {float(d.max()):.3e} (|y| max {float(ref.abs().max()):.2f})")
+    assert float(d.max()) <= 2.0 ** -9 * float(ref.abs().max()) and frac_equal > 0.9
+
+
 @pytest.mark.parametrize("shape,splits", [((8, 64, 64, 256, 256), 256), ((8, 64, 128, 128, 128), 256), ((8, 128, 128, 128, 128), 128),
                                           ((8, 192, 64, 256, 256), 80)])
 def test_wgrad16_production_shapes_exact_integers(mau, shape, splits):
