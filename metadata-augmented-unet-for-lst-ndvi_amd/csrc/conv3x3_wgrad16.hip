@@ -135,6 +135,16 @@ __global__ __launch_bounds__((BCO / 64) * 4 * KG * 64) void wgrad16_kernel(Wgrad
       const int k = id & ((1 << xcd_shift) - 1), j = id >> xcd_shift;
       tile_id = j % tilesOut;
       split = ((j / tilesOut) << xcd_shift) + k;
+    } else if (xcd_shift < 0) {
+      // any other split count: the (split, tile) list in split-major order is cut into one contiguous run per XCD -- the tiles of a
+      // split are still resident on one XCD (two at a run boundary) at about the same time.  The grid is rounded up to a whole number
+      // of workgroups per XCD; the (at most XCDs - 1) surplus workgroups leave here, before any barrier.
+      const int sh = -xcd_shift, k = id & ((1 << sh) - 1), j = id >> sh;
+      const int total = nsplit * tilesOut, per = (total + (1 << sh) - 1) >> sh;
+      const int w = k * per + j;
+      if (w >= total) return;
+      split = w / tilesOut;
+      tile_id = w - split * tilesOut;
     } else {
       split = id % nsplit;
       tile_id = id / nsplit;
@@ -405,7 +415,9 @@ static int launch(const WgradP& p, int nsplit, int xcd_shift, hipStream_t st) {
   constexpr size_t lds = 2 * stage > red ? 2 * stage : red;
   static_assert(lds <= 160 * 1024, "LDS budget");
   MAU_LDS_ATTR(lds, &wgrad16_kernel<BCO, KG, F16, MIXED>);
-  dim3 grid(nsplit * (p.CoutPad / BCO) * (p.CinPad / BCI));
+  const int total = nsplit * (p.CoutPad / BCO) * (p.CinPad / BCI);
+  // (xcd_shift < 0: a whole number of workgroups per XCD; the surplus ones return at once -- conv3x3_wgrad_bf16.hip wgrad_grid)
+  dim3 grid(xcd_shift < 0 ? (((total + (1 << -xcd_shift) - 1) >> -xcd_shift) << -xcd_shift) : total);
   MAU_LAUNCH((wgrad16_kernel<BCO, KG, F16, MIXED>), grid, dim3(NW * 64), lds, st, p, nsplit, xcd_shift);
   return check_launch("wgrad16_kernel");
 }

@@ -151,6 +151,16 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
       const int k = id & ((1 << xcd_shift) - 1), j = id >> xcd_shift;
       tile_id = j % tilesOut;
       split = ((j / tilesOut) << xcd_shift) + k;
+    } else if (xcd_shift < 0) {
+      // any other split count: the (split, tile) list in split-major order is cut into one contiguous run per XCD -- the tiles of a
+      // split are still resident on one XCD (two at a run boundary) at about the same time.  The grid is rounded up to a whole number
+      // of workgroups per XCD; the (at most XCDs - 1) surplus workgroups leave here, before any barrier.
+      const int sh = -xcd_shift, k = id & ((1 << sh) - 1), j = id >> sh;
+      const int total = nsplit * tilesOut, per = (total + (1 << sh) - 1) >> sh;
+      const int w = k * per + j;
+      if (w >= total) return;
+      split = w / tilesOut;
+      tile_id = w - split * tilesOut;
     } else {
       split = id % nsplit;
       tile_id = id / nsplit;
@@ -353,8 +363,22 @@ __global__ __launch_bounds__(BCO * 4 * KG) void wgrad_bf16_kernel(WgradP p, int 
     }
 }
 
-// (the XCD-contiguous work-item order and whole split counts per XCD; round 3 A/B'd it against id = split + nsplit * tile: kept)
+// The kernels' work-item order for a split count (speed only: every (split, tile) computes the same slab whatever its workgroup id).
+//   > 0 : XCD k owns the splits = k (mod XCDs) -- split counts that are whole numbers per XCD (round 3);
+//   < 0 : the split-major (split, tile) list is cut into one contiguous run per XCD -- ANY other count (round 6); the grid is rounded
+//         up to a whole number of workgroups per XCD and the surplus ones return at once;
+//     0 : a device with one XCD: plain order id = split + nsplit * tile.
+// Either way the workgroups of one split -- which stream the SAME pixels -- are resident on one XCD at about the same time.
 static inline bool wgrad_xcd_order() { return true; }
+static inline int wgrad_xcd_shift(int nsplit, int tilesOut) {
+  const DeviceShape ds = device_shape();
+  if (ds.xcds <= 1) return 0;
+  return nsplit % ds.xcds == 0 ? ds.xcd_shift : -ds.xcd_shift;
+}
+static inline int wgrad_grid(int nsplit, int tilesOut, int xcd_shift) {
+  const int total = nsplit * tilesOut;
+  return xcd_shift < 0 ? (((total + (1 << -xcd_shift) - 1) >> -xcd_shift) << -xcd_shift) : total;
+}
 
 template <int BCO, int KG, bool F16, int NS>
 static int launch(const WgradP& p, int nsplit, hipStream_t st) {
@@ -367,9 +391,8 @@ static int launch(const WgradP& p, int nsplit, hipStream_t st) {
   constexpr size_t lds = NS * stage > red ? NS * stage : red;
   static_assert(lds <= 160 * 1024, "LDS budget");
   MAU_LDS_ATTR(lds, &wgrad_bf16_kernel<BCO, KG, F16, NS>);
-  const DeviceShape ds = device_shape();
-  const int xcd_shift = (wgrad_xcd_order() && ds.xcds > 1 && nsplit % ds.xcds == 0) ? ds.xcd_shift : 0;
-  dim3 grid(nsplit * (p.CoutPad / BCO) * (p.CinPad / BCI));
+  const int xcd_shift = wgrad_xcd_shift(nsplit, (p.CoutPad / BCO) * (p.CinPad / BCI));
+  dim3 grid(wgrad_grid(nsplit, (p.CoutPad / BCO) * (p.CinPad / BCI), xcd_shift));
   MAU_LAUNCH((wgrad_bf16_kernel<BCO, KG, F16, NS>), grid, dim3(BCO * 4 * KG), lds, st, p, nsplit, xcd_shift);
   return check_launch("wgrad_bf16_kernel");
 }
@@ -425,13 +448,11 @@ int wgrad_bf16_v2_splits(int N, int H, int W, int Cout, int Cin) {
   int best = 1;
   double best_cost = 1e300;
   const long cus = launch_cus();
-  const int xcds = wg2::wgrad_xcd_order() ? device_shape().xcds : 1;
   const double ov = v.k16 ? 16.0 : 10.0;
   for (int s = 1; s <= smax; ++s) {                // s = workgroups along the split axis = partial slabs
-    if (s >= xcds && s % xcds != 0) continue;      // whole splits per XCD (see the kernel's work-item order)
     const long blocks = (long)outTiles * s;
-    const long rounds = (blocks + cus - 1) / cus;
-    const double cost = (double)rounds * ((double)ceil_div(nTiles, s) + ov) * ((xcds > 1 && s % xcds != 0 && outTiles >= xcds) ? 1.10 : 1.0);
+    const long rounds = (blocks + cus - 1) / cus;      // (every split count has an XCD-contiguous work-item order: wgrad_xcd_shift)
+    const double cost = (double)rounds * ((double)ceil_div(nTiles, s) + ov);
     if (cost < best_cost - 1e-9 * (best_cost < 0 ? -best_cost : best_cost)) {
       best_cost = cost;
       best = s;
@@ -453,9 +474,8 @@ int launch_wgrad_bf16_v2(const WgradP& p, bool f16, hipStream_t st) {
   q.tilesY = ceil_div(p.H, v.th);
   q.nTiles = p.N * q.tilesX * q.tilesY;
   if (v.k16) {
-    const DeviceShape ds = device_shape();
-    const int xcd_shift = (wg2::wgrad_xcd_order() && ds.xcds > 1 && nsplit % ds.xcds == 0) ? ds.xcd_shift : 0;
-    return launch_wgrad16(q, f16, mixed, nsplit, xcd_shift, st);
+    const int bco = p.CoutPad % 128 == 0 ? 128 : 64;
+    return launch_wgrad16(q, f16, mixed, nsplit, wg2::wgrad_xcd_shift(nsplit, (p.CoutPad / bco) * (p.CinPad / 64)), st);
   }
 #ifndef WG_NS64
 #define WG_NS64 2

@@ -262,6 +262,15 @@ def test_graphed_inference_matches_eager(mau, model_type):
     assert torch.equal(sess(*b), ref_b)
     with pytest.raises(ValueError):
         sess(torch.zeros(2, 23, 96, 96, device="cuda"), b[1], b[2])
+    # host tensors go straight into the session's buffers (one copy, not host -> device -> buffer); a caller that fills ``sess.inputs``
+    # itself pays no copy at all; ``clone_output=False`` hands out the session's own output buffer
+    assert torch.equal(sess(*(t_.cpu() for t_ in a)), ref_a)
+    for dst, src in zip(sess.inputs, b):
+        dst.copy_(src)
+    assert torch.equal(sess(*sess.inputs), ref_b)
+    sess2 = mau.GraphedInference(net, *a, clone_output=False)
+    o1 = sess2(*a)
+    assert torch.equal(o1, ref_a) and sess2(*b).data_ptr() == o1.data_ptr() and torch.equal(o1, ref_b)
 
 
 @pytest.mark.parametrize("opt_kw", [dict(fused=True), dict(foreach=True)])
