@@ -277,6 +277,42 @@ constexpr bool ABL_NOWDMA = true;
 #else
 constexpr bool ABL_NOWDMA = false;
 #endif
+// TIMING-ONLY probe (round 6; never in the product build): what "BatchNorm-apply + ReLU fused into the consumer's load" would cost with
+// THIS loader -- an LDS-DMA has no register stage, so the affine map + ReLU would have to run as a fix-up pass over the halo image in
+// LDS between "the stage has landed" and "its fragments are read": every wave rewrites its share of the (TH + 2) x 18 pixels x 16
+// channels (16-byte vectors: read, unpack, fma, max, pack, write; all-zero vectors -- the padding ring -- stay zero), then one more
+// workgroup barrier per stage.  Coefficients are register constants here (a real kernel reloads 32 of them per stage): a LOWER bound.
+// Results are garbage (relu of the input); scripts/r6_c5.sh times it.  EXPERIMENTS.md "Round 6", DESIGN.md section 8.
+#ifdef MAU_CONV_PROBE_LDSFIX
+constexpr bool PROBE_LDSFIX = true;
+#else
+constexpr bool PROBE_LDSFIX = false;
+#endif
+template <int VECS, int THREADS, bool F16>
+__device__ __forceinline__ void probe_lds_fix(unsigned buf, int tid, float sc, float sh) {
+#pragma unroll
+  for (int it = 0; it < (VECS + THREADS - 1) / THREADS; ++it) {
+    const int v = tid + it * THREADS;
+    if (v < VECS) {
+      const unsigned a = buf + (unsigned)v * 16u;
+      u32x4 r = lds_read_u128<0>(a);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r));
+      const bool keep = (r[0] | r[1] | r[2] | r[3]) != 0u;
+      u32x4 o;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        f32x2 x = {__uint_as_float(r[d] << 16), __uint_as_float(r[d] & 0xffff0000u)};
+        x = __builtin_elementwise_fma(x, f32x2{sc, sc}, f32x2{sh, sh});
+        x = f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+        o[d] = keep ? pack_lp2<F16>(x) : 0u;
+      }
+      asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(o) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // The same wave-DMA through a buffer resource: address = base (SGPR resource) + soff (SGPR: the stage's channel / slab
 // offset) + voff (per lane, constant over the stages of an item); a lane whose voff is 0xffffffff is out of range and
 // receives zeros (hardware range check: the zero padding of the convolution and of the slot grid, no zero page).  One
@@ -563,6 +599,11 @@ __global__ __launch_bounds__(NW * KG * 64, 2) void conv3x3_bf16_kernel(ConvP p, 
         const bool moreB = chunk + 2 < p.nChunks;
         const int fchunkB = moreB ? chunk + 2 : 0;
         const unsigned sA = lds0 + stage * STAGE, sB = lds0 + (stage ^ 1) * STAGE;
+        if constexpr (PROBE_LDSFIX) {                           // (timing probe: stage A's halo image, published by the barrier above)
+          float psc = 1.0009765625f, psh = 0.0009765625f;
+          asm volatile("" : "+v"(psc), "+v"(psh));
+          probe_lds_fix<HPIX * 2, NW * 64, F16>(sA, tid, psc, psh);
+        }
         bf16x8 fa[PS::RA] = {}, fb[PS::RB] = {};
         unsigned aAddr = 0, bAddr = 0;
         auto issue_read = [&](auto kc) {
@@ -599,6 +640,11 @@ __global__ __launch_bounds__(NW * KG * 64, 2) void conv3x3_bf16_kernel(ConvP p, 
             wait_vmcnt<0>();
 #endif
             __builtin_amdgcn_s_barrier();
+            if constexpr (PROBE_LDSFIX) {                         // (timing probe: stage B's halo image, just published)
+              float psc = 1.0009765625f, psh = 0.0009765625f;
+              asm volatile("" : "+v"(psc), "+v"(psh));
+              probe_lds_fix<HPIX * 2, NW * 64, F16>(sB, tid, psc, psh);
+            }
           }
           if constexpr (M == PS::B2) {                              // stage A's buffer: everyone is done reading it
             __builtin_amdgcn_s_barrier();
