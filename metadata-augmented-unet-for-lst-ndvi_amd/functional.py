@@ -386,7 +386,7 @@ class ConvBNReLU(torch.autograd.Function):
                      1x1 head reads the raw conv output and applies BatchNorm + ReLU on the fly, forward and backward;
       * ``up_to`` -- returns up(activation) (bilinear x2, align_corners=True, src/model.py:219,279-282) instead of the
                      activation: the resize applies BatchNorm + ReLU to the four corners it loads.
-    ``MAU_FUSED_BN=0`` runs the same variants through the separate kernels (bit-identical; the A/B and test switch)."""
+    ``functional._FUSED_BN = False`` (a test hook) runs the same variants through the separate kernels, bit-identical."""
 
     @staticmethod
     def forward(ctx, x, x1, emb, weight, bias, gamma, beta, rmean, rvar, nbt, hw, hb, st: BNState):

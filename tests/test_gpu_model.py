@@ -865,7 +865,7 @@ def test_weight_gradient_stream_is_bitwise_neutral(mau, monkeypatch):
 def test_single_launch_reductions_and_multi_pack_are_bit_identical(mau, monkeypatch):
     """Launch-tail fusions of round 3 against the forms they replace, same arithmetic in the same order: the single-launch slab
     reductions (ticket: the last workgroup runs the second level; functional._FUSED_REDUCE) vs two launches, and the one-launch
-    multi-tensor weight pack (functional.PackGroup; MAU_PACK_MULTI) vs one launch per layer: two training steps, everything equal."""
+    multi-tensor weight pack (functional.PackGroup; functional._PACK_MULTI) vs one launch per layer: two training steps, everything equal."""
     from mau_amd import functional as F_
     g = torch.Generator().manual_seed(71)
     x, ts, md = torch.randn(4, 6, 96, 80, generator=g).cuda(), torch.randn(4, 10, generator=g).cuda(), torch.randn(4, 4, generator=g).cuda()

@@ -695,7 +695,7 @@ def test_fused_bn_backward_matches_unfused(mau, model_type, size, base, prec, mo
     pool + skip backward without a ``da`` tensor, the 1x1 head reading the raw conv output forward and backward, the decoder /
     bottleneck blocks returning up(output).  The fused kernels recompute exactly what the separate kernels store (rounded to the
     activation type) and keep the reductions' geometry and order: outputs, loss, EVERY gradient and the BatchNorm buffers of a
-    training step must equal the unfused path (MAU_FUSED_BN=0 semantics) bit for bit -- even (x2 upsample exact) and odd sizes
+    training step must equal the unfused path (functional._FUSED_BN = False) bit for bit -- even (x2 upsample exact) and odd sizes
     (pool windows that do not cover the last row / column, second resize), 64-channel heads and narrow ones, all three dtypes."""
     from mau_amd import functional as F_
     if prec == "fp32" and model_type == "unet++":
