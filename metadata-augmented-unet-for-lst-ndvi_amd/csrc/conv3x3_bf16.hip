@@ -282,7 +282,7 @@ constexpr bool ABL_NOWDMA = false;
 // LDS between "the stage has landed" and "its fragments are read": every wave rewrites its share of the (TH + 2) x 18 pixels x 16
 // channels (16-byte vectors: read, unpack, fma, max, pack, write; all-zero vectors -- the padding ring -- stay zero), then one more
 // workgroup barrier per stage.  Coefficients are register constants here (a real kernel reloads 32 of them per stage): a LOWER bound.
-// Results are garbage (relu of the input); scripts/r6_c5.sh times it.  EXPERIMENTS.md "Round 6", DESIGN.md section 8.
+// Results are garbage (relu of the input); scripts/archive/r6_c5.sh times it.  EXPERIMENTS.md "Round 6", DESIGN.md section 8.
 #ifdef MAU_CONV_PROBE_LDSFIX
 constexpr bool PROBE_LDSFIX = true;
 #else
