@@ -46,7 +46,8 @@ typedef void* mau_stream_t;
 
 /* ---- library ---------------------------------------------------------- */
 #define MAU_ABI_VERSION 5  /* 2: single-launch reductions (tickets), multi-tensor weight pack, fused BatchNorm passes; 3: first-layer kernels;
-                            * 4: mau_set_cu_budget (an experiment, measured a loss); 5: mau_set_cu_budget removed, mau_conv3x3_variant reports K groups */
+                            * 4: mau_set_cu_budget (an experiment, measured a loss); 5: mau_set_cu_budget removed, mau_conv3x3_variant reports K groups,
+                            *    mau_conv3x3_fwd_pool */
 int mau_abi_version(void);
 const char* mau_last_error(void);
 /* 0 when the current HIP device is a gfx950 (MI355X); MAU_ERR_DEVICE otherwise. */
@@ -95,6 +96,14 @@ int mau_conv3x3_pack_weights_multi(const void* descs, int n, int total_tiles, in
  * channels: one per 8x16-pixel tile for MAU_F32; one per (workgroup tile of 16x16 or 32x16 pixels, wave row) for
  * MAU_BF16 -- the tile height is chosen per layer from how well its work items fill the 256 CUs. */
 int mau_conv3x3_num_pixel_tiles(int dtype, int N, int H, int W, int Cout);
+/* Inference form of an ENCODER block's second convolution (reference src/model.py:18-21 in eval mode, then `self.pool`, :218,268-271):
+ * y = relu(post_scale * (conv3x3(x) + bias) + post_shift) as mau_conv3x3_fwd writes it AND pooled = MaxPool2d(2,2)(y) (floor mode),
+ * (N, H/2, W/2, ldpool), in one launch: the 16-bit epilogues take the window maxima from the registers they store (activations are
+ * >= 0, whose 16-bit patterns order like integers); MAU_F32 runs mau_maxpool2x2_fwd behind the convolution -- the same bits as the two
+ * calls either way.  One tensor source (no x1, no broadcast embedding). */
+int mau_conv3x3_fwd_pool(const void* x, int ldx, int C0, const void* wpk, const float* bias, const float* post_scale,
+                         const float* post_shift, void* y, int ldy, int Cout, void* pooled, int ldpool, int dtype, int N, int H,
+                         int W, mau_stream_t stream);
 /* Which tile variant of the convolution kernel runs such a layer (diagnostics and tests: "did the big-tile variant run?"):
  * pixel rows of a workgroup tile (16 pixels wide), waves per workgroup, output channels per workgroup -- written to HOST ints.
  * 16-bit: (64,8,64) = <64,4,8>, (32,4,64) = <64,4,4> (two workgroups per CU, level 0), (32,8,128) = <128,4,8>, (16,..) / (8,..) =

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "mau_conv3x3_first_wgrad": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mau_conv3x3_first_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_fwd": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "mau_conv3x3_fwd_pool": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _p]),
     "mau_conv3x3_fwd2": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "mau_conv3x3_wgrad_splits": (_i, [_i, _i, _i, _i, _i, _i]),
     "mau_conv3x3_wgrad_acc_elems": (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -746,9 +746,9 @@ int mau_head_bn_bwd_apply(const void* y, int ldy, const float* scale, const floa
   MAU_REQUIRE(ldy % 8 == 0 && ldy >= C8 && lddy % 8 == 0 && lddy >= C8, "head_bn_bwd_apply: bad ld");
   MAU_REQUIRE(HW >= 32 && (int64_t)N * HW < ((int64_t)1 << 31), "head_bn_bwd_apply: images of at least 32 pixels, fewer than 2^31 pixels in all");
   const int64_t npix = (int64_t)N * HW;
-  // 32 (8) pixels per thread: the coefficient set-up is paid once per thread.  (Round 6, same call: 2048 pixels per workgroup 144 -> 131 us,
-  //  4096 -> 161 us, the arithmetic on register pairs +-0 -- profiles/r6/head_apply_variants.txt; 13 us, not taken into the record library.)
-  const int pixb = npix >= ((int64_t)1 << 20) ? 1024 : 256;
+  // 64 (8) pixels per thread: the coefficient set-up is paid once per thread.  (Round 6, same call: 1024 pixels per workgroup 144 us, 2048
+  //  131 us, 4096 161 us; the arithmetic on register pairs +-0 -- profiles/r6/head_apply_variants.txt.)
+  const int pixb = npix >= ((int64_t)1 << 20) ? 2048 : 256;
 #define MAU_HEAD_APPLY(MC_, EX_)                                                                                                            \
   MAU_DISPATCH_DTYPE(dtype, MAU_LAUNCH((head_bn_bwd_apply_kernel<T, MC_, EX_>), dim3(ceil_div(npix, pixb)), dim3(256), 0, (hipStream_t)stream, (const T*)y, ldy, \
                                        scale, shift, mean, invstd, sums, count > 0 ? 1.0 / count : 0.0, w, out, dout, (T*)dy, lddy, tanh0, HW, C, Co, npix, pixb))

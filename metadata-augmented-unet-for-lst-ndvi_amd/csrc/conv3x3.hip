@@ -592,6 +592,29 @@ int mau_conv3x3_fwd2(const void* x, int ldx, int C0, const void* x1, int ldx1, i
   return MAU_ERR_ARG;
 }
 
+int mau_conv3x3_fwd_pool(const void* x, int ldx, int C0, const void* wpk, const float* bias, const float* post_scale, const float* post_shift,
+                         void* y, int ldy, int Cout, void* pooled, int ldpool, int dtype, int N, int H, int W, mau_stream_t stream) {
+  MAU_REQUIRE(x && wpk && y && pooled && post_scale && post_shift, "conv3x3_fwd_pool: null pointer");
+  MAU_REQUIRE(N > 0 && H >= 2 && W >= 2 && C0 > 0 && Cout > 0, "conv3x3_fwd_pool: bad shape");
+  MAU_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldpool % 8 == 0 && ldx >= C0 && ldy >= Cout && ldpool >= round_up(Cout, 8),
+              "conv3x3_fwd_pool: ld must be a multiple of 8 and >= C");
+  MAU_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)wpk % 16) == 0 && ((uintptr_t)pooled % 16) == 0,
+              "conv3x3_fwd_pool: pointers must be 16-byte aligned");
+  if (dtype == MAU_F32) {                              // parity mode: the two launches
+    const int rc = mau_conv3x3_fwd2(x, ldx, C0, nullptr, 0, 0, nullptr, nullptr, 0, wpk, bias, post_scale, post_shift, y, ldy, Cout, nullptr, dtype, N, H, W, stream);
+    return rc != MAU_OK ? rc : mau_maxpool2x2_fwd(y, ldy, pooled, ldpool, dtype, N, H, W, Cout, stream);
+  }
+  MAU_REQUIRE(dtype == MAU_BF16 || dtype == MAU_F16, "bad dtype %d", dtype);
+  ConvP p;
+  p.x = x; p.ldx = ldx; p.C0 = C0; p.x1 = nullptr; p.ldx1 = 0; p.C1 = 0;
+  p.emb = nullptr; p.emb_lp = nullptr; p.E = 0; p.w = wpk; p.bias = bias; p.post_scale = post_scale; p.post_shift = post_shift; p.y = y; p.ldy = ldy;
+  p.Cout = Cout; p.CoutPad = round_up(Cout, 64); p.slab = nullptr; p.N = N; p.H = H; p.W = W;
+  p.tilesX = ceil_div(W, TW); p.tilesY = ceil_div(H, TH);
+  p.nChunks = ceil_div(C0, mau_conv3x3_kc(dtype));
+  p.pool = pooled; p.ldpool = ldpool;
+  return launch_conv_bf16_v2(p, dtype == MAU_F16, (hipStream_t)stream);
+}
+
 int mau_conv3x3_fwd(const void* x, int ldx, int C0, const float* emb, void* emb_ws, int E, const void* wpk,
                     const float* bias, const float* post_scale, const float* post_shift, void* y, int ldy, int Cout,
                     float* slab, int dtype, int N, int H, int W, mau_stream_t stream) {

@@ -788,6 +788,36 @@ __global__ __launch_bounds__(NW * KG * 64, 2) void conv3x3_bf16_kernel(ConvP p, 
     const unsigned stg = lds0 + (stage ^ 1) * STAGE + wave * (32 * 64 * 2);
     const unsigned rbase = stg + (lane >> 3) * 128 + (lane & 7) * 16;   // read: pixel pass*8 + lane/8, 16-byte vector lane%8
     const int cv = cur.co0 + wn * 64 + (lane & 7) * 8;
+    // MaxPool2d(2,2) of the activation (reference src/model.py:218,268-271; inference epilogue) from the SAME registers a tile-row group
+    // is stored from: a group is two pixel rows of 16, ov[pass] = row pass / 2, pixel x = 8 (pass % 2) + lane / 8, 8 channels per lane
+    // -- the row partner of a pixel is the same lane two passes on, its column partner the lane 8 further (DPP row_ror:8 inside the
+    // 16-lane row).  The activation is relu(...) >= 0, and the bit patterns of non-negative bf16 / fp16 values order like signed 16-bit
+    // integers (-0 below everything): v_pk_max_i16 on the packed pairs IS the maximum, bit for bit what mau_maxpool2x2_fwd computes
+    // from the stored tensor.  ybase (the group's first row) is even; floor mode: windows that leave the image do not exist.
+    auto pool_group = [&](const u32x4 (&ov)[4], int ybase, bool whole) {
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      auto mx = [](unsigned a, unsigned b) -> unsigned {
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+      };
+      const int Ho = p.H >> 1, Wo = p.W >> 1;
+      const int yq = ybase >> 1;
+      unsigned char* const pbytes = reinterpret_cast<unsigned char*>(p.pool);
+      int lane_p = lane;                       // (opaque per group: nothing below may be hoisted out of the item loop into a
+      asm volatile("" : "+v"(lane_p));         //  register that lives across the multiply loop -- the file is full at 256)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {                                        // pixels x = 0..7 | 8..15 of the two rows
+        u32x4 v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned m = mx(ov[half][d], ov[half + 2][d]);
+          v[d] = mx(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, false));     // row_ror:8 -> lane ^ 8
+        }
+        const int xq = (cur.tx0 >> 1) + half * 4 + (lane_p >> 4);
+        const bool mine = ((lane_p >> 3) & 1) == 0 && cur.co0 + wn * 64 + (lane_p & 7) * 8 < p.ldpool && (whole || (yq < Ho && xq < Wo));
+        if (mine)
+          *reinterpret_cast<u32x4*>(pbytes + ((((size_t)cur.n * Ho + yq) * Wo + xq) * p.ldpool + cur.co0 + wn * 64 + (lane_p & 7) * 8) * 2) = v;
+      }
+    };
     if constexpr (M16) {
 #ifdef MAU_CONV_ABL_NOEPI            // timing-only: the accumulators are consumed, nothing is staged, counted or stored
       float t = 0.f;
@@ -849,6 +879,9 @@ __global__ __launch_bounds__(NW * KG * 64, 2) void conv3x3_bf16_kernel(ConvP p, 
               if (FULL || (gyu < p.H && gxu + (lane >> 3) < p.W))
                 __builtin_nontemporal_store(ov[pass], reinterpret_cast<u32x4*>(ybytes + uni + lane_off));
             }
+          }
+          if constexpr (EPI == EPI_POST && ONE) {         // (single-source forms only: an encoder block's second convolution)
+            if (p.pool != nullptr) pool_group(ov, ybase, FULL);
           }
 #endif
         };
@@ -1017,8 +1050,8 @@ __global__ __launch_bounds__(NW * KG * 64, 2) void conv3x3_bf16_kernel(ConvP p, 
       u32x4 o0 = lds_read_u128<0 * 1024>(rbase), o1 = lds_read_u128<1 * 1024>(rbase);
       u32x4 o2 = lds_read_u128<2 * 1024>(rbase), o3 = lds_read_u128<3 * 1024>(rbase);
       lds_land(o0, o1, o2, o3);
+      const u32x4 ov[4] = {o0, o1, o2, o3};
       if (cv < p.ldy) {
-        const u32x4 ov[4] = {o0, o1, o2, o3};
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
           const int prow = pass * 8 + (lane >> 3);
@@ -1026,6 +1059,9 @@ __global__ __launch_bounds__(NW * KG * 64, 2) void conv3x3_bf16_kernel(ConvP p, 
           if (full || (gy < p.H && gx < p.W))
             __builtin_nontemporal_store(ov[pass], reinterpret_cast<u32x4*>(yg + ((size_t)(cur.n * p.H + gy) * p.W + gx) * p.ldy + cv));
         }
+      }
+      if constexpr (EPI == EPI_POST) {
+        if (p.pool != nullptr) pool_group(ov, ybase, full);
       }
     }
 #endif
@@ -1105,6 +1141,10 @@ static int launch(const ConvP& p, hipStream_t st) {
   // (MAU_CONV_M16=0: the 32x32x16 loop everywhere -- the exact big-tile tests run both loops on the production tilings)
   static const bool m16 = getenv("MAU_CONV_M16") == nullptr || atoi(getenv("MAU_CONV_M16")) != 0;
   bool done = false;
+  // MaxPool2d(2,2) of the activation (inference, one tensor source): written by the epilogue from the registers it stores; anything else
+  // runs the convolution as it is and mau_maxpool2x2_fwd behind it (same bits)
+  const bool pool_behind = q.pool != nullptr && !(EPI == EPI_POST && p.C1 == 0 && p.E == 0);
+  if (pool_behind) q.pool = nullptr;
   if constexpr (MT == 4) {
     if (m16 && q.fast && q.nChunks % 2 == 0) {
       if (p.C1 == 0 && p.E == 0)
@@ -1129,7 +1169,9 @@ static int launch(const ConvP& p, hipStream_t st) {
   } else {
     MAU_LAUNCH((conv3x3_bf16_kernel<BN, MT, NW, EPI, F16, false, false>), dim3(grid), dim3(NW * 64), G::LDS, st, q, nPixTiles, nCt, nItems);
   }
-  return check_launch("conv3x3_bf16_kernel");
+  const int rc = check_launch("conv3x3_bf16_kernel");
+  if (rc != MAU_OK || !pool_behind) return rc;
+  return mau_maxpool2x2_fwd(p.y, p.ldy, p.pool, p.ldpool, F16 ? MAU_F16 : MAU_BF16, p.N, p.H, p.W, p.Cout, (mau_stream_t)st);
 }
 
 // Variant choice.  Taller workgroup tiles move fewer LDS-DMA bytes and issue fewer ds_reads per MFMA (measured

@@ -38,6 +38,8 @@ struct ConvP {
   int N, H, W, tilesX, tilesY, nChunks;
   int xcdShift;         // log2(XCDs of the device) for the XCD-contiguous work-item order (bf16 kernel, set by its launcher)
   int fast;             // (bf16 kernel, set by its launcher) every 16-channel stage lies inside one tensor: buffer-addressed loader
+  void* pool = nullptr; // optional (inference epilogue of the 16x16x32 tilings): MaxPool2d(2,2) of the activation, (N, H/2, W/2, ldpool)
+  int ldpool = 0;
 };
 
 // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)

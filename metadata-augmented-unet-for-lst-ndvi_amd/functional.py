@@ -338,6 +338,7 @@ _FUSED_REDUCE = True        # single-launch slab reductions (tickets)
 _FUSED_BN = True            # BatchNorm passes fused with pool / head / upsample
 _FUSED_UP = True            # (the upsample member of the above, separately switchable)
 _PACK_MULTI = True          # one multi-tensor weight-pack launch per optimizer step (functional.PackGroup)
+_INFER_POOL_FUSED = True    # inference: an encoder block's max-pool out of the convolution's epilogue (mau_conv3x3_fwd_pool)
 _FIRST_WGRAD = True         # the first layer's weight gradient on its own kernel (csrc/conv3x3_first.hip)
 _SIDE_STREAMS = {}
 
@@ -473,8 +474,15 @@ class ConvBNReLU(torch.autograd.Function):
                     fz["scale"], fz["shift"] = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
                 call("mau_bn_coeffs_eval", gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(),
                      st.eps, fz["scale"].data_ptr(), fz["shift"].data_ptr(), None, None, Cout, stream)
+            pl = None
             if first:
                 first_fwd((fz["scale"], fz["shift"]), y, None, None)
+            elif st.pool and _INFER_POOL_FUSED and x1 is None and not E and H >= 2 and W >= 2:
+                # an encoder block's second convolution: the pooled tensor comes out of the same launch (the 16x16x32 tilings take the
+                # 2x2 maxima from the registers they store; other tilings run the pooling kernel behind the convolution inside the call)
+                pl = torch.empty((N, H // 2, W // 2, ldy), dtype=act_dt, device=dev)
+                call("mau_conv3x3_fwd_pool", x.data_ptr(), _ld(x), st.C0, fz["wf"].data_ptr(), bias.data_ptr() if bias is not None else None,
+                     fz["scale"].data_ptr(), fz["shift"].data_ptr(), y.data_ptr(), _ld(y), Cout, pl.data_ptr(), ldy, code, N, H, W, stream)
             else:
                 _conv_fwd(x, x1, st, emb, emb_ws, E, fz["wf"], bias, (fz["scale"], fz["shift"]), y, Cout, None, code, N, H, W, stream)
             if st.head is not None:
@@ -487,7 +495,8 @@ class ConvBNReLU(torch.autograd.Function):
                 return up
             ctx.mark_non_differentiable(y)
             if st.pool:
-                pl = pooled_of(y)
+                if pl is None:
+                    pl = pooled_of(y)
                 ctx.mark_non_differentiable(pl)
                 return y, pl
             return y

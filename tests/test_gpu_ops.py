@@ -179,6 +179,43 @@ def test_conv3x3_k_group_variants_exact(mau, dt, shape):
     assert torch.equal(got, post if float(post.abs().max()) < lim else post.to(dt).float())
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(8, 64, 64, 256, 256), (4, 128, 128, 128, 128), (16, 256, 256, 64, 64), (2, 64, 64, 250, 131),
+                                   (3, 64, 64, 48, 40), (1, 512, 512, 32, 32), (2, 48, 64, 64, 64)])
+def test_conv3x3_fwd_pool_matches_conv_then_maxpool(mau, dt, shape):
+    """``mau_conv3x3_fwd_pool`` (inference form of an encoder block's second convolution: the 2 x 2 maxima taken from the registers the
+    16x16x32 epilogue stores) against ``mau_conv3x3_fwd`` + ``mau_maxpool2x2_fwd``: activation AND pooled tensor bit for bit, on
+    real-valued data with negative pre-activations (ReLU zeros, -0 candidates), full and ragged images (odd sizes: the floor-mode
+    windows that do not exist), the two big tilings that fuse (<64,4,4>, <128,4,8>) and shapes that take the two-launch route inside
+    the call (small images, an odd stage count)."""
+    from mau_amd import functional as F_
+    from mau_amd._lib import call
+    N, Cin, Cout, H, W = shape
+    code = F_.dtype_code(dt)
+    g = torch.Generator().manual_seed(sum(shape) + 77)
+    x = torch.randn(N, H, W, Cin, generator=g).cuda().to(dt)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    sc = ((torch.rand(Cout, generator=g) + 0.5) * (1 - 2 * (torch.arange(Cout) % 7 == 0).float())).cuda()
+    sh = torch.randn(Cout, generator=g).cuda()
+    wf = F_.pack_conv_weights(w, code)[0]
+    st = torch.cuda.current_stream().cuda_stream
+    y0 = torch.empty((N, H, W, Cout), dtype=dt, device="cuda")
+    p0 = torch.empty((N, H // 2, W // 2, Cout), dtype=dt, device="cuda")
+    call("mau_conv3x3_fwd", x.data_ptr(), Cin, Cin, None, None, 0, wf.data_ptr(), b.data_ptr(), sc.data_ptr(), sh.data_ptr(), y0.data_ptr(), Cout, Cout,
+         None, code, N, H, W, st)
+    call("mau_maxpool2x2_fwd", y0.data_ptr(), Cout, p0.data_ptr(), Cout, code, N, H, W, Cout, st)
+    y1 = torch.full_like(y0, float("nan"))
+    p1 = torch.full_like(p0, float("nan"))
+    call("mau_conv3x3_fwd_pool", x.data_ptr(), Cin, Cin, wf.data_ptr(), b.data_ptr(), sc.data_ptr(), sh.data_ptr(), y1.data_ptr(), Cout, Cout,
+         p1.data_ptr(), Cout, code, N, H, W, st)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16))
+    assert torch.equal(p1.view(torch.int16), p0.view(torch.int16))
+    ref = torch.nn.functional.max_pool2d(y0.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.equal(p1.float(), ref) and float(p1.float().max()) > 0
+
+
 def test_conv3x3_k_groups_against_one_group_on_real_data(mau, tmp_path):
     """the two-K-group form changes the summation order (group 0's stages + group 1's stages), and integer data cannot see
     that.  Real-valued data, B = 1 conv4_0.conv2 of the 512 x 512 network (1024 -> 1024 at 32 x 32, fp16, inference epilogue): the
